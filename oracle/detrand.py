@@ -1,0 +1,72 @@
+"""Deterministic, platform-independent tensor generator (test infrastructure).
+
+Values come from a splitmix64 integer hash of (key, element index); four 16-bit uniforms are
+summed (Irwin-Hall) to give an approximately normal variate using only exactly-representable
+float64 arithmetic, so the same numbers appear on every host and fixtures only need to store
+reference OUTPUTS, never weights or inputs.
+"""
+import zlib
+import numpy as np
+import torch
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M
+        return z ^ (z >> np.uint64(31))
+
+
+def _key(name: str, seed: int) -> np.uint64:
+    return np.uint64((zlib.crc32(name.encode()) << 20) ^ (seed * 0x9E3779B1 & 0xFFFFFFFF))
+
+
+def normal(name: str, shape, seed: int = 0, std: float = 1.0, dtype=torch.float32) -> torch.Tensor:
+    n = int(np.prod(shape)) if len(shape) else 1
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + _key(name, seed)
+    h = _splitmix64(idx)
+    s = np.zeros(n, dtype=np.float64)
+    for k in range(4):
+        s += ((h >> np.uint64(16 * k)) & np.uint64(0xFFFF)).astype(np.float64)
+    # each term uniform on {0..65535}: mean 32767.5, var (65536^2-1)/12
+    z = (s - 4 * 32767.5) / np.sqrt(4 * (65536.0 ** 2 - 1) / 12.0)
+    return torch.from_numpy((z * std).reshape(shape)).to(dtype)
+
+
+def uniform(name: str, shape, seed: int = 0, lo: float = 0.0, hi: float = 1.0, dtype=torch.float32) -> torch.Tensor:
+    n = int(np.prod(shape)) if len(shape) else 1
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + _key(name, seed)
+    h = _splitmix64(idx)
+    u = ((h >> np.uint64(11)).astype(np.float64) + 0.5) / float(1 << 53)
+    return torch.from_numpy((lo + (hi - lo) * u).reshape(shape)).to(dtype)
+
+
+def randint(name: str, shape, lo: int, hi: int, seed: int = 0) -> torch.Tensor:
+    """integers in [lo, hi)"""
+    u = uniform(name, shape, seed, dtype=torch.float64)
+    return (u * (hi - lo)).floor().long() + lo
+
+
+def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
+    """Random-looking weights for every tensor of a UNet state_dict.
+
+    Conv/linear weights ~ N(0, 1/fan_in) (no zero-initialised tensors, so no path is hidden
+    behind zeros -- reference trap at unet.py:71,125,232); norm weights ~ 1 + 0.1 N; biases 0.1 N.
+    """
+    out = {}
+    for name, shp in shapes.items():
+        shp = tuple(shp)
+        if len(shp) >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            out[name] = normal(name, shp, seed, std=fan_in ** -0.5)
+        elif "norm" in name and name.endswith("weight") or name.startswith("out_conv.0.weight"):
+            out[name] = 1.0 + normal(name, shp, seed, std=0.1)
+        else:
+            out[name] = normal(name, shp, seed, std=0.1)
+    return out
