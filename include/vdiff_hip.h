@@ -1,0 +1,177 @@
+/* vdiff_hip.h -- C ABI of libvdiff_hip.so: the MI355X (gfx950) kernels behind the
+ * v-diffusion hot path (UNet forward/backward inside the diffusion train step + the DDIM/CFG
+ * sampling loop of tqch/v-diffusion-torch).
+ *
+ * The reference has no FFI layer: its hot path bottoms out in ATen calls.  Each entry point
+ * below replaces one of those call sites (cited as reference file:line) and is what a binding
+ * of this path has to import -- see INTEGRATION.md for the ctypes stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch types.  All tensors are fp32 unless stated.
+ *  - activations are NHWC: [image][y][x][channel] with an explicit per-pixel stride `ld`
+ *    (in floats, multiple of 4, base 16-byte aligned) so channel slices of a wider buffer
+ *    (the "virtual concat" of reference unet.py:315) can be read/written in place.
+ *  - the library never allocates, frees or retains device memory; scratch comes in through
+ *    `ws` arguments (size from the matching *_ws_bytes query).  Every launch goes to the
+ *    `stream` argument (a hipStream_t passed as void*).  No host synchronisation anywhere,
+ *    so every call is HIP-graph capturable.
+ *  - return value: 0 on success, non-zero on error; vd_last_error() gives the message of
+ *    the calling thread's last failure.
+ */
+#ifndef VDIFF_HIP_H
+#define VDIFF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VD_VERSION 100
+
+int         vd_version(void);
+const char* vd_last_error(void);
+
+/* ------------------------------------------------------------------ dense contractions (MFMA fp32)
+ * One tile engine (v_mfma_f32_32x32x2_f32, LDS-staged, double buffered) behind every
+ * matmul-shaped op of the path.  C[z][m][n] = alpha * sum_k A(z,m,k) * B(z,n,k) (+bias[n]) (+R[z][m][n]) (+C) */
+enum { VD_ROW = 0,      /* operand stored [rows][k], k contiguous                                  */
+       VD_COL = 1,      /* operand stored [k][rows], rows contiguous                               */
+       VD_IM2COL = 2 }; /* A: 3x3 patches of an NHWC image, k = (tap, channel)  (conv forward/dgrad)
+                           B: 3x3 patches, k = pixel, n = (tap, channel)         (conv wgrad)       */
+
+typedef struct vd_gemm_desc {
+    const float* A; const float* B; float* C;
+    const float* bias;          /* [N] or NULL                                                      */
+    const float* R;             /* residual, same indexing as C with ldr / sR*, or NULL             */
+    int32_t M, N, K;
+    int32_t a_kind, b_kind;
+    int64_t lda, ldb, ldc, ldr;
+    int32_t batch, nh;          /* z in [0,batch): zb = z / nh, zh = z % nh (nh >= 1)               */
+    int64_t sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh;
+    float   alpha;
+    int32_t accumulate;         /* C += result                                                      */
+    int32_t H, W, Cin;          /* image geometry for VD_IM2COL                                     */
+    int32_t splitk;             /* >1: K is split over `splitk` slabs in ws, then reduced into C    */
+    float*  ws; int64_t ws_bytes;
+    int32_t tile;               /* 0 = auto, 128 or 64 forces the block tile                        */
+} vd_gemm_desc;
+
+/* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two
+ * einsum contractions of attention (unet.py:57,61-63) and all of their autograd backward GEMMs */
+int vd_gemm(const vd_gemm_desc* d, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution, NHWC (replaces F.conv2d at modules.py:141-144 <- unet.py:121,125,217,232).
+ *   y[b,y,x,co] = bias[co] + res[b,y,x,co] + sum_{tap,ci} xin[b,y+dy,x+dx,ci] * wpack[co][tap][ci]
+ * wpack comes from vd_pack_conv3x3 ("forward" pack for the forward pass, "dgrad" pack for the input gradient).
+ * Cin must be a multiple of 4 (pad 3 -> 4); only co < Cout is written. */
+int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, const float* bias,
+               const float* res, int64_t ldres, float* y, int64_t ldy,
+               int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate, void* stream);
+
+/* weight gradient of the same convolution, summed over the whole batch (autograd of F.conv2d):
+ *   dw_oihw[co][ci][tap] (+)= sum_{b,y,x} dy[b,y,x,co] * xin[b,y+dy,x+dx,ci]      co < Cout_w, ci < Cin_w
+ * xin has Cin (multiple of 4, >= Cin_w) channels, dy has Cout (multiple of 4, >= Cout_w) channels. */
+size_t vd_conv3x3_wgrad_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t lddy,
+                     int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                     float* dw_oihw, int32_t Cin_w, int32_t Cout_w, int32_t accumulate,
+                     float* ws, size_t ws_bytes, void* stream);
+
+/* OIHW (Cout_w, Cin_w, 3, 3) -> wf[Cout_w][9][Cin_p]  (forward)  and/or  wd[Cin_w][9][Cout_p] with the taps
+ * mirrored (dgrad).  Either output may be NULL.  Padding channels are zero-filled. */
+int vd_pack_conv3x3(const float* w_oihw, int32_t Cout_w, int32_t Cin_w,
+                    float* wf, int32_t Cin_p, float* wd, int32_t Cout_p, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm(32, C, eps) + SiLU + FiLM + dropout + resample
+ * (nn.GroupNorm unet.py:28-30, nn.SiLU unet.py:25, FiLM unet.py:145-146, nn.Dropout unet.py:135,147,
+ *  nn.AvgPool2d / nn.Upsample unet.py:127-132) */
+enum { VD_RS_NONE = 0, VD_RS_DOWN = 1, VD_RS_UP = 2 };
+
+/* per-(image, group) mean and 1/sqrt(var+eps) of x[nimg][HW][C]; stats = [nimg][G][2] */
+size_t vd_gn_ws_bytes(int32_t nimg, int32_t HW, int32_t C);
+int vd_gn_stats(const float* x, int64_t ldx, int32_t nimg, int32_t HW, int32_t C, int32_t G, float eps,
+                float* stats, float* ws, size_t ws_bytes, void* stream);
+
+/* y = resample( dropout( act( (1+scale) * GN(x) + shift ) ) )
+ * film: [nimg][2C] (shift first, scale second, unet.py:145) or NULL; act: 1 = SiLU, 0 = identity;
+ * gamma/beta NULL => plain resample of x (the skip path, unet.py:138).
+ * coef: scratch [nimg][4][C] floats, kept for the backward pass. */
+int vd_gn_apply(const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                const float* film, int32_t act, float p_drop, uint64_t seed,
+                int32_t resample, float* y, int64_t ldy,
+                int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* coef, void* stream);
+
+/* backward of vd_gn_apply.  dy is at the OUTPUT resolution of the forward op.
+ *   dx (+)= d/dx ; dfilm [nimg][2C] (written) ; dgamma/dbeta (+)= (accumulate_params)
+ * add: optional tensor (input resolution, ld = ldadd) added into dx (the skip-path gradient). */
+int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef,
+                    const float* gamma, const float* beta, const float* film, int32_t act, float p_drop, uint64_t seed,
+                    int32_t resample, const float* add, int64_t ldadd, float* dx, int64_t lddx, int32_t accumulate_dx,
+                    float* dfilm, float* dgamma, float* dbeta, int32_t accumulate_params,
+                    int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G,
+                    float* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ small reductions / elementwise
+ * out[n] (+)= sum_m x[m][n]   (bias gradients) */
+size_t vd_colsum_ws_bytes(int64_t M, int32_t N);
+int vd_colsum(const float* x, int64_t ldx, int64_t M, int32_t N, float* out, int32_t accumulate,
+              float* ws, size_t ws_bytes, void* stream);
+/* y = alpha*x + beta*y over [rows][C] with strides */
+int vd_axpby(const float* x, int64_t ldx, float alpha, float* y, int64_t ldy, float beta, int64_t rows, int32_t C, void* stream);
+/* SiLU forward / backward on a dense vector (nn.SiLU on t_emb, unet.py:142,203) */
+int vd_silu(const float* x, float* y, int64_t n, void* stream);
+int vd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, int32_t accumulate, void* stream);
+/* row softmax in place over [rows][L] (torch.softmax unet.py:58-59) and its backward: ds = alpha * p * (dp - sum(dp*p)) */
+int vd_softmax_rows(float* s, int64_t rows, int32_t L, void* stream);
+int vd_softmax_rows_bwd(const float* p, float* dp, int64_t rows, int32_t L, float alpha, void* stream);
+
+/* layout changes at the boundary of the NCHW call surface */
+int vd_nchw_to_nhwc(const float* x, float* y, int32_t nimg, int32_t C, int32_t H, int32_t W, int64_t ldy, void* stream);
+int vd_nhwc_to_nchw(const float* x, int64_t ldx, float* y, int32_t nimg, int32_t C, int32_t H, int32_t W, void* stream);
+
+/* ------------------------------------------------------------------ embeddings
+ * get_timestep_embedding (functions.py:11-29): fp64 arithmetic, fp32 result [n][dim] */
+int vd_timestep_embedding(const double* t, float* out, int32_t n, int32_t dim, double scale, void* stream);
+/* OneHot(exclude_zero) + Linear (modules.py:184-201, unet.py:209-215,295): temb[b] += W[:, y-1] (y>0) + bias */
+int vd_class_embed(const float* y, const float* w, const float* bias, float* temb, int32_t n, int32_t emb, int32_t ncls, void* stream);
+int vd_class_embed_bwd(const float* y, const float* dtemb, float* dw, float* dbias, int32_t n, int32_t emb, int32_t ncls,
+                       int32_t accumulate, void* stream);
+/* multitag normalisation y / sqrt(max(nnz,1)) (unet.py:290-294) */
+int vd_multitag_norm(const float* y, float* out, int32_t n, int32_t ncls, void* stream);
+
+/* ------------------------------------------------------------------ diffusion process (diffusion.py)
+ * model_out_type: 0 = v, 1 = x0, 2 = eps, 3 = both ; reweight: 0 = constant, 1 = snr, 2 = snr_trunc, 3 = snr_1plus */
+/* q_sample (diffusion.py:242-245): xt_nhwc[b,y,x,0..C) = sqrt(sigmoid(l_b)) x0 + sqrt(sigmoid(-l_b)) eps, NCHW in, NHWC(ld) out */
+int vd_q_sample(const float* x0_nchw, const float* eps_nchw, const float* logsnr, float* xt_nhwc, int64_t ld,
+                float* xt_nchw_opt, int32_t n, int32_t C, int32_t HW, void* stream);
+/* train_loss mse branch (diffusion.py:520-541): per-sample loss[n]; aux[n][2] keeps the two branch means */
+int vd_loss_fwd(const float* x0_nchw, const float* eps_nchw, const float* xt_nhwc, int64_t ldxt,
+                const float* out_nhwc, int64_t ldo, const float* logsnr,
+                int32_t model_out_type, int32_t reweight, float* loss, float* aux, int32_t n, int32_t C, int32_t HW, void* stream);
+/* d loss / d model_out, scaled by gloss[n]; written NHWC (ld) with padding channels zeroed */
+int vd_loss_bwd(const float* x0_nchw, const float* eps_nchw, const float* xt_nhwc, int64_t ldxt,
+                const float* out_nhwc, int64_t ldo, const float* logsnr, const float* aux, const float* gloss,
+                int32_t model_out_type, int32_t reweight, float* dout_nhwc, int64_t lddo, int32_t ldpad,
+                int32_t n, int32_t C, int32_t HW, void* stream);
+/* one reverse step (p_mean_var + CFG + noise, diffusion.py:317-392) for a whole batch that shares the step index.
+ * out_nhwc has `rows = n * (1 + cfg)` images (cond/uncond interleaved when cfg).  k: 8 host-computed floats
+ * {alpha_t, sigma_t, aux_t0, aux_t1, c1, c2, noise_scale, w_guide}; see diffusion.py in the host package.
+ * Writes the new state as NHWC (ld) for the next UNet call, duplicated/interleaved when cfg_next_dup. */
+int vd_sample_step(const float* xt_nhwc, int64_t ldx, const float* out_nhwc, int64_t ldo, const float* noise_nchw,
+                   const float* k, int32_t model_out_type, int32_t cfg, int32_t last_step, int32_t clip,
+                   float* xnext_nhwc, int64_t ldn, int32_t dup_next, float* xnext_nchw_opt,
+                   int32_t n, int32_t C, int32_t HW, void* stream);
+
+/* ------------------------------------------------------------------ optimizer tail (train_utils.py:159-168, utils.py:144-149)
+ * sum of squares of a flat buffer (global-norm clip), fused clip + AdamW + EMA over flat fp32 buffers */
+size_t vd_sumsq_ws_bytes(int64_t n);
+int vd_sumsq(const float* g, int64_t n, float* out1, float* ws, size_t ws_bytes, void* stream);
+int vd_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n,
+                 const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                 float bc1, float bc2, float ema_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

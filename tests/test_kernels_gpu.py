@@ -1,0 +1,435 @@
+"""Per-kernel parity tests of libvdiff_hip.so, called through the C ABI (ctypes), against plain PyTorch CPU
+references of the same op (fp64 as truth, torch fp32 as the natural-noise yardstick).  Need an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from v_diffusion import _hip
+    _hip.lib()
+    return _hip
+
+
+def rnd(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 7919 * len(shape) + sum(shape))
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def close(got, ref64, ref32=None, slack=4.0, floor=2e-6, name=""):
+    """|got - ref64| must be within `slack` x the error torch's own fp32 result has (plus a relative floor)."""
+    got = got.detach().cpu().double()
+    ref64 = ref64.detach().double()
+    scale = max(ref64.abs().max().item(), 1e-30)
+    err = (got - ref64).abs().max().item()
+    nat = 0.0 if ref32 is None else (ref32.detach().double() - ref64).abs().max().item()
+    tol = slack * nat + floor * scale
+    assert math.isfinite(err) and err <= tol, f"{name}: max err {err:.3e} > tol {tol:.3e} (natural fp32 noise {nat:.3e}, scale {scale:.3e})"
+    return err
+
+
+# ------------------------------------------------------------------------------------------------ GEMM engine
+GEMM_SHAPES = [(128, 128, 32), (64, 64, 64), (200, 72, 100), (256, 512, 1024), (1024, 256, 2304), (36, 4, 8), (132, 260, 36)]
+
+
+@pytest.mark.parametrize("a_kind,b_kind", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_kinds(H, a_kind, b_kind, M, N, K, tile):
+    A = rnd(M, K, seed=1)
+    B = rnd(N, K, seed=2)
+    bias = rnd(N, seed=3)
+    R = rnd(M, N, seed=4)
+    ref64 = 0.5 * (A.double() @ B.double().T) + bias.double() + R.double()
+    ref32 = 0.5 * (A @ B.T) + bias + R
+    Ad = (A if a_kind == 0 else A.T.contiguous()).to(DEV)
+    Bd = (B if b_kind == 0 else B.T.contiguous()).to(DEV)
+    Cd = torch.full((M, N + 4), 7.0, device=DEV)                # ldc > N: untouched padding must survive
+    H.gemm(Ad, Bd, Cd, M, N, K, a_kind=a_kind, b_kind=b_kind, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N + 4,
+           bias=bias.to(DEV), R=R.to(DEV), ldr=N, alpha=0.5, tile=tile)
+    torch.cuda.synchronize()
+    close(Cd[:, :N], ref64, ref32, name=f"gemm{a_kind}{b_kind}")
+    assert (Cd[:, N:] == 7.0).all()
+
+
+def test_gemm_batched_heads_accumulate(H):
+    Bz, nh, L, hd = 3, 2, 64, 32
+    qkv = rnd(Bz, L, 3 * nh * hd, seed=5)
+    q = qkv[..., : nh * hd].reshape(Bz, L, nh, hd)
+    k = qkv[..., nh * hd: 2 * nh * hd].reshape(Bz, L, nh, hd)
+    ref64 = torch.einsum("blnc,bmnc->bnlm", q.double(), k.double()) / math.sqrt(hd)
+    qd = qkv.to(DEV)
+    S = torch.ones(Bz, nh, L, L, device=DEV)
+    ld = 3 * nh * hd
+    H.gemm(qd, qd[0, 0, nh * hd:], S, L, L, hd, a_kind=0, b_kind=0, lda=ld, ldb=ld, ldc=L, batch=Bz * nh, nh=nh,
+           sA=(L * ld, hd), sB=(L * ld, hd), sC=(nh * L * L, L * L), alpha=1 / math.sqrt(hd), accumulate=True)
+    torch.cuda.synchronize()
+    close(S, ref64 + 1.0, None, floor=3e-6, name="batched QK^T")
+
+
+@pytest.mark.parametrize("kinds", [(1, 1), (0, 0), (0, 1)])
+def test_gemm_splitk(H, kinds):
+    a_kind, b_kind = kinds
+    M, N, K = 64, 96, 4096
+    A, B = rnd(M, K, seed=6), rnd(N, K, seed=7)
+    ref64, ref32 = A.double() @ B.double().T, A @ B.T
+    Ad = (A if a_kind == 0 else A.T.contiguous()).to(DEV)
+    Bd = (B if b_kind == 0 else B.T.contiguous()).to(DEV)
+    Cd = torch.ones(M, N, device=DEV)
+    H.gemm(Ad, Bd, Cd, M, N, K, a_kind=a_kind, b_kind=b_kind, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, splitk=8, accumulate=True)
+    torch.cuda.synchronize()
+    close(Cd, ref64 + 1.0, ref32 + 1.0, name="splitk")
+
+
+def test_gemm_rejects_bad_input(H):
+    A = torch.zeros(8, 6, device=DEV)
+    with pytest.raises(RuntimeError):
+        H.gemm(A, A, A, 8, 8, 6, lda=6, ldb=6, ldc=8)          # lda not a multiple of 4
+    with pytest.raises(RuntimeError):
+        H.gemm(torch.zeros(4, 4), A, A, 4, 4, 4, lda=4, ldb=4, ldc=4)   # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------------ conv 3x3
+def nhwc(x, ld=None):
+    """NCHW cpu -> NHWC device tensor with per-pixel stride ld (extra channels filled with NaN-free junk)."""
+    B, Cc, Hh, Ww = x.shape
+    ld = ld or Cc
+    out = torch.full((B, Hh, Ww, ld), 3.0)
+    out[..., :Cc] = x.permute(0, 2, 3, 1)
+    return out.to(DEV)
+
+
+def from_nhwc(y, Cc):
+    return y[..., :Cc].permute(0, 3, 1, 2).cpu()
+
+
+CONV_CASES = [  # nimg, H, W, Cin, Cout, ldx_extra, ldy_extra
+    (2, 8, 8, 32, 64, 0, 0), (3, 16, 16, 64, 32, 32, 64), (1, 32, 32, 256, 256, 0, 0), (2, 16, 16, 4, 32, 0, 0),
+    (2, 8, 8, 32, 3, 0, 1), (2, 4, 4, 96, 160, 0, 0), (5, 8, 8, 36, 68, 4, 4), (1, 2, 2, 8, 8, 0, 0), (2, 64, 64, 32, 32, 0, 0)]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_forward(H, case):
+    nimg, Hh, Ww, Cin, Cout, ex, ey = case
+    x, w, b = rnd(nimg, Cin, Hh, Ww, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=3)
+    res = rnd(nimg, Cout, Hh, Ww, seed=4)
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    ref32 = F.conv2d(x, w, b, padding=1) + res
+    xd, rd = nhwc(x, Cin + ex), nhwc(res, Cout + ey)
+    wf = torch.empty(Cout, 9, Cin, device=DEV)
+    H.pack_conv3x3(w.to(DEV), Cout, Cin, wf=wf, Cin_p=Cin)
+    y = torch.full((nimg, Hh, Ww, Cout + ey), 5.0, device=DEV)
+    H.conv3x3(xd, Cin + ex, wf, b.to(DEV), y, Cout + ey, nimg, Hh, Ww, Cin, Cout, res=rd, ldres=Cout + ey)
+    torch.cuda.synchronize()
+    close(from_nhwc(y, Cout), ref64, ref32, name="conv fwd")
+    if ey:
+        assert (y[..., Cout:] == 5.0).all()
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 64), (2, 16, 16, 64, 32), (1, 32, 32, 256, 256), (2, 8, 8, 32, 4)])
+def test_conv3x3_dgrad(H, case):
+    nimg, Hh, Ww, Cin, Cout = case
+    Cw = 3 if Cout == 4 else Cout                # out_conv: 3 real output channels padded to 4
+    x = rnd(nimg, Cin, Hh, Ww, seed=1).double().requires_grad_(True)
+    w = rnd(Cw, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    dy = rnd(nimg, Cw, Hh, Ww, seed=3)
+    F.conv2d(x, w.double(), padding=1).backward(dy.double())
+    x32 = x.detach().float().requires_grad_(True)
+    F.conv2d(x32, w, padding=1).backward(dy)
+    wd = torch.empty(Cin, 9, Cout, device=DEV)
+    H.pack_conv3x3(w.to(DEV), Cw, Cin, wd=wd, Cout_p=Cout)
+    dyp = torch.zeros(nimg, Cout, Hh, Ww)
+    dyp[:, :Cw] = dy
+    dx = torch.empty(nimg, Hh, Ww, Cin, device=DEV)
+    H.conv3x3(nhwc(dyp), Cout, wd, None, dx, Cin, nimg, Hh, Ww, Cout, Cin)
+    torch.cuda.synchronize()
+    close(from_nhwc(dx, Cin), x.grad, x32.grad, name="conv dgrad")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 64, 32, 64), (4, 16, 16, 64, 32, 64, 32), (2, 32, 32, 256, 256, 256, 256),
+                                  (3, 16, 16, 4, 32, 3, 32), (3, 8, 8, 32, 4, 32, 3), (8, 32, 32, 32, 32, 32, 32)])
+def test_conv3x3_wgrad(H, case):
+    nimg, Hh, Ww, Cin, Cout, Cin_w, Cout_w = case
+    x = torch.zeros(nimg, Cin, Hh, Ww)
+    x[:, :Cin_w] = rnd(nimg, Cin_w, Hh, Ww, seed=1)
+    dy = torch.zeros(nimg, Cout, Hh, Ww)
+    dy[:, :Cout_w] = rnd(nimg, Cout_w, Hh, Ww, seed=2)
+    w64 = torch.zeros(Cout_w, Cin_w, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[:, :Cin_w].double(), w64, padding=1).backward(dy[:, :Cout_w].double())
+    w32 = torch.zeros(Cout_w, Cin_w, 3, 3, requires_grad=True)
+    F.conv2d(x[:, :Cin_w], w32, padding=1).backward(dy[:, :Cout_w])
+    dw = torch.ones(Cout_w, Cin_w, 3, 3, device=DEV)
+    H.conv3x3_wgrad(nhwc(x), Cin, nhwc(dy), Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin_w, Cout_w, accumulate=True)
+    torch.cuda.synchronize()
+    close(dw, w64.grad + 1.0, w32.grad + 1.0, name="conv wgrad")
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm family
+def ref_gn_block(x, gamma, beta, film, act, resample, mask=None):
+    B, Cc = x.shape[:2]
+    h = F.group_norm(x, 32, gamma, beta, 1e-6)
+    if film is not None:
+        shift, scale = film[:, :Cc, None, None], film[:, Cc:, None, None]
+        h = (1 + scale) * h + shift
+    if act:
+        h = F.silu(h)
+    if mask is not None:
+        h = h * mask
+    if resample == 1:
+        h = F.avg_pool2d(h, 2)
+    elif resample == 2:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    return h
+
+
+GN_CASES = [  # nimg, C, H, W, film, act, resample
+    (2, 64, 8, 8, False, True, 0), (3, 96, 8, 8, True, True, 0), (2, 256, 16, 16, True, True, 0), (2, 64, 8, 8, False, True, 1),
+    (2, 64, 8, 8, False, True, 2), (2, 128, 4, 4, False, False, 0), (1, 1152, 8, 8, True, True, 0), (2, 192, 32, 32, False, True, 1)]
+
+
+@pytest.mark.parametrize("case", GN_CASES)
+def test_gn_forward_backward(H, case):
+    nimg, Cc, Hh, Ww, use_film, act, rs = case
+    x = rnd(nimg, Cc, Hh, Ww, seed=1) * 1.5 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(Cc, seed=2), 0.1 * rnd(Cc, seed=3)
+    film = 0.3 * rnd(nimg, 2 * Cc, seed=4) if use_film else None
+    Ho, Wo = (Hh // 2, Ww // 2) if rs == 1 else ((Hh * 2, Ww * 2) if rs == 2 else (Hh, Ww))
+    dy = rnd(nimg, Cc, Ho, Wo, seed=5)
+    add = rnd(nimg, Cc, Hh, Ww, seed=6)
+
+    def run(dt):
+        xs, g, b_ = x.to(dt).requires_grad_(True), gamma.to(dt).requires_grad_(True), beta.to(dt).requires_grad_(True)
+        fl = None if film is None else film.to(dt).requires_grad_(True)
+        out = ref_gn_block(xs, g, b_, fl, act, rs)
+        out.backward(dy.to(dt))
+        return out.detach(), xs.grad + add.to(dt), g.grad, b_.grad, (None if fl is None else fl.grad)
+    o64, dx64, dg64, db64, df64 = run(torch.float64)
+    o32, dx32, dg32, db32, df32 = run(torch.float32)
+
+    ldx = Cc + 8
+    xd = nhwc(x, ldx)
+    stats = torch.empty(nimg, 32, 2, device=DEV)
+    H.gn_stats(xd, ldx, nimg, Hh * Ww, Cc, stats)
+    coef = torch.empty(nimg, 4, Cc, device=DEV)
+    y = torch.empty(nimg, Ho, Wo, Cc, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    fd = None if film is None else film.to(DEV)
+    H.gn_apply(xd, ldx, stats, gd, bd, fd, act, 0.0, 0, rs, y, Cc, nimg, Hh, Ww, Cc, coef)
+    torch.cuda.synchronize()
+    mean64 = x.double().reshape(nimg, 32, -1).mean(-1)
+    close(stats[..., 0], mean64, None, floor=1e-6, name="gn mean")
+    close(from_nhwc(y, Cc), o64, o32, name="gn fwd")
+
+    dx = torch.full((nimg, Hh, Ww, Cc), 1.0, device=DEV)
+    dfilm = None if film is None else torch.empty(nimg, 2 * Cc, device=DEV)
+    dgam, dbet = torch.ones(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    H.gn_apply_bwd(nhwc(dy), Cc, xd, ldx, coef, gd, bd, fd, act, 0.0, 0, rs, nhwc(add), Cc, dx, Cc, True, dfilm, dgam, dbet,
+                   True, nimg, Hh, Ww, Cc)
+    torch.cuda.synchronize()
+    close(from_nhwc(dx, Cc), dx64 + 1.0, dx32 + 1.0, slack=6, floor=5e-6, name="gn dx")
+    close(dgam, dg64 + 1.0, dg32 + 1.0, slack=6, floor=5e-6, name="dgamma")
+    close(dbet, db64 + 1.0, db32 + 1.0, slack=6, floor=5e-6, name="dbeta")
+    if film is not None:
+        close(dfilm, df64, df32, slack=6, floor=5e-6, name="dfilm")
+
+
+@pytest.mark.parametrize("rs", [0, 1, 2])
+def test_plain_resample_and_backward(H, rs):
+    nimg, Cc, Hh, Ww = 2, 64, 8, 8
+    x = rnd(nimg, Cc, Hh, Ww, seed=1)
+    ref = F.avg_pool2d(x, 2) if rs == 1 else (F.interpolate(x, scale_factor=2, mode="nearest") if rs == 2 else x)
+    Ho, Wo = ref.shape[2:]
+    y = torch.empty(nimg, Ho, Wo, Cc, device=DEV)
+    H.gn_apply(nhwc(x), Cc, None, None, None, None, 0, 0.0, 0, rs, y, Cc, nimg, Hh, Ww, Cc, None)
+    close(from_nhwc(y, Cc), ref.double(), ref, name="resample")
+    dy = rnd(nimg, Cc, Ho, Wo, seed=2)
+    xs = x.double().requires_grad_(True)
+    r = F.avg_pool2d(xs, 2) if rs == 1 else (F.interpolate(xs, scale_factor=2, mode="nearest") if rs == 2 else xs * 1)
+    r.backward(dy.double())
+    dx = torch.empty(nimg, Hh, Ww, Cc, device=DEV)
+    H.gn_apply_bwd(nhwc(dy), Cc, None, 0, None, None, None, None, 0, 0.0, 0, rs, None, 0, dx, Cc, False, None, None, None, False,
+                   nimg, Hh, Ww, Cc)
+    close(from_nhwc(dx, Cc), xs.grad, xs.grad.float(), name="resample bwd")
+
+
+def test_dropout_mask_is_consistent_and_bernoulli(H):
+    nimg, Cc, Hh, Ww, p = 4, 128, 16, 16, 0.2
+    x = rnd(nimg, Cc, Hh, Ww, seed=1) + 3.0            # keep activations away from 0
+    gamma, beta = torch.ones(Cc), torch.zeros(Cc)
+    xd = nhwc(x)
+    stats = torch.empty(nimg, 32, 2, device=DEV)
+    H.gn_stats(xd, Cc, nimg, Hh * Ww, Cc, stats)
+    coef = torch.empty(nimg, 4, Cc, device=DEV)
+    y0, y1, y2 = (torch.empty(nimg, Hh, Ww, Cc, device=DEV) for _ in range(3))
+    H.gn_apply(xd, Cc, stats, gamma.to(DEV), beta.to(DEV), None, 0, 0.0, 0, 0, y0, Cc, nimg, Hh, Ww, Cc, coef)
+    H.gn_apply(xd, Cc, stats, gamma.to(DEV), beta.to(DEV), None, 0, p, 1234, 0, y1, Cc, nimg, Hh, Ww, Cc, coef)
+    H.gn_apply(xd, Cc, stats, gamma.to(DEV), beta.to(DEV), None, 0, p, 1235, 0, y2, Cc, nimg, Hh, Ww, Cc, coef)
+    keep = (y1 != 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+    torch.testing.assert_close(y1[keep], (y0 / (1 - p))[keep], rtol=1e-6, atol=1e-6)
+    assert ((y2 != 0) != keep).float().mean().item() > 0.2           # a different seed gives a different mask
+    # replay the mask through the torch reference: backward must use the same mask
+    mask = from_nhwc(keep.float() / (1 - p), Cc).double()
+    xs = x.double().requires_grad_(True)
+    dy = rnd(nimg, Cc, Hh, Ww, seed=2)
+    (F.group_norm(xs, 32, gamma.double(), beta.double(), 1e-6) * mask).backward(dy.double())
+    dx = torch.empty(nimg, Hh, Ww, Cc, device=DEV)
+    dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    H.gn_apply_bwd(nhwc(dy), Cc, xd, Cc, coef, gamma.to(DEV), beta.to(DEV), None, 0, p, 1234, 0, None, 0, dx, Cc, False, None,
+                   dg, db, False, nimg, Hh, Ww, Cc)
+    close(from_nhwc(dx, Cc), xs.grad, None, floor=2e-5, name="dropout bwd")
+
+
+# ------------------------------------------------------------------------------------------------ small kernels
+def test_colsum_axpby_silu(H):
+    x = rnd(1000, 72, seed=1)
+    xd = torch.zeros(1000, 80, device=DEV)
+    xd[:, :72] = x.to(DEV)
+    out = torch.ones(72, device=DEV)
+    H.colsum(xd, 80, 1000, 72, out, accumulate=True)
+    close(out, x.double().sum(0) + 1, x.sum(0) + 1, name="colsum")
+    y = rnd(1000, 72, seed=2)
+    yd = y.to(DEV)
+    H.axpby(xd, 80, 0.5, yd, 72, 2.0, 1000, 72)
+    close(yd, 0.5 * x.double() + 2.0 * y.double(), None, name="axpby")
+    v = rnd(5000, seed=3) * 3
+    vd, od = v.to(DEV), torch.empty(5000, device=DEV)
+    H.silu(vd, od)
+    close(od, F.silu(v.double()), F.silu(v), name="silu")
+    vs = v.double().requires_grad_(True)
+    g = rnd(5000, seed=4)
+    F.silu(vs).backward(g.double())
+    gd = torch.ones(5000, device=DEV)
+    H.silu_bwd(vd, g.to(DEV), gd, accumulate=True)
+    close(gd, vs.grad + 1, None, floor=3e-6, name="silu bwd")
+
+
+@pytest.mark.parametrize("L", [64, 256, 1000, 4096])
+def test_softmax_rows(H, L):
+    rows = 37
+    s = rnd(rows, L, seed=1) * 4
+    p64 = torch.softmax(s.double(), -1)
+    sd = s.to(DEV)
+    H.softmax_rows(sd, rows, L)
+    close(sd, p64, torch.softmax(s, -1), name="softmax")
+    dp = rnd(rows, L, seed=2)
+    ss = s.double().requires_grad_(True)
+    torch.softmax(0.25 * ss, -1).backward(dp.double())           # ds = alpha * p*(dp - sum(dp*p))
+    pd = torch.softmax(0.25 * s.double(), -1).float().to(DEV)
+    dpd = dp.to(DEV)
+    H.softmax_rows_bwd(pd, dpd, rows, L, 0.25)
+    close(dpd, ss.grad, None, floor=3e-6, name="softmax bwd")
+
+
+def test_layout_roundtrip(H):
+    x = rnd(3, 3, 8, 8, seed=1)
+    y = torch.full((3, 8, 8, 4), 9.0, device=DEV)
+    H.nchw_to_nhwc(x.to(DEV), y, 3, 3, 8, 8, 4)
+    assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1)) and (y[..., 3] == 0).all()
+    z = torch.empty(3, 3, 8, 8, device=DEV)
+    H.nhwc_to_nchw(y, 4, z, 3, 3, 8, 8)
+    assert torch.equal(z.cpu(), x)
+
+
+def test_timestep_embedding_matches_oracle(H):
+    from oracle.unet_ref import timestep_embedding
+    t = torch.tensor([0.0, 1e-3, 0.25, 0.5, 0.999, 1.0, 0.123456789], dtype=torch.float64)
+    for dim in (256, 192, 33):
+        out = torch.empty(len(t), dim, device=DEV)
+        H.timestep_embedding(t.to(DEV), out, len(t), dim)
+        ref = timestep_embedding(t, dim)
+        assert (out.cpu() - ref).abs().max().item() <= 2e-7
+
+
+def test_class_embed_and_multitag(H):
+    n, emb, ncls = 9, 64, 10
+    y = torch.tensor([0., 1., 10., 3., 3., 0., 7., 10., 5.])
+    w, b, te = rnd(emb, ncls, seed=1), rnd(emb, seed=2), rnd(n, emb, seed=3)
+    oh = F.one_hot((y.long() - 1).clamp(min=0), ncls).double() * (y != 0).double()[:, None]
+    ws = w.double().requires_grad_(True)
+    bs = b.double().requires_grad_(True)
+    ref = te.double() + F.linear(oh, ws, bs)
+    g = rnd(n, emb, seed=4)
+    ref.backward(g.double())
+    ted = te.to(DEV)
+    H.class_embed(y.to(DEV), w.to(DEV), b.to(DEV), ted, n, emb, ncls)
+    close(ted, ref.detach(), None, name="class embed")
+    dw, db = torch.ones(emb, ncls, device=DEV), torch.ones(emb, device=DEV)
+    H.class_embed_bwd(y.to(DEV), g.to(DEV), dw, db, n, emb, ncls, accumulate=True)
+    close(dw, ws.grad + 1, None, name="class dw")
+    close(db, bs.grad + 1, None, name="class db")
+    tags = (rnd(6, 40, seed=5) > 0.8).float()
+    tags[0] = 0
+    out = torch.empty(6, 40, device=DEV)
+    H.multitag_norm(tags.to(DEV), out, 6, 40)
+    ref = tags / torch.count_nonzero(tags, dim=1).clamp(min=1.0).sqrt().unsqueeze(1)
+    close(out, ref.double(), ref, name="multitag")
+
+
+# ------------------------------------------------------------------------------------------------ diffusion kernels
+@pytest.mark.parametrize("mot,rw", [("v", "snr_trunc"), ("v", "snr_1plus"), ("v", "constant"), ("v", "snr"), ("x0", "snr_trunc"),
+                                    ("eps", "snr_trunc"), ("both", "snr_trunc"), ("eps", "snr"), ("x0", "constant")])
+def test_qsample_loss_fwd_bwd(H, mot, rw):
+    from oracle import diffusion_ref as dref
+    n, Cc, R = 5, 3, 8
+    Co = 6 if mot == "both" else 3
+    ldo = 8 if mot == "both" else 4
+    x0, eps = rnd(n, Cc, R, R, seed=1).clamp(-1, 1), rnd(n, Cc, R, R, seed=2)
+    t = torch.tensor([0.02, 0.3, 0.5, 0.8, 0.97], dtype=torch.float64)
+    logsnr = dref.make_schedule("cosine")(t).float()
+    out = rnd(n, Co, R, R, seed=3)
+    o64 = out.double().requires_grad_(True)
+    loss64 = dref.train_loss(lambda a, b, c: o64, lambda tt: logsnr.double(), x0.double(), t, None, eps.double(), mot, rw)
+    gl = rnd(n, seed=4)
+    (loss64 * gl.double()).sum().backward()
+    loss32 = dref.train_loss(lambda a, b, c: out, lambda tt: logsnr, x0, t, None, eps, mot, rw)
+    xt = torch.full((n, R, R, 4), 9.0, device=DEV)
+    xt_nchw = torch.empty(n, Cc, R, R, device=DEV)
+    H.q_sample(x0.to(DEV), eps.to(DEV), logsnr.to(DEV), xt, 4, xt_nchw, n, Cc, R * R)
+    ref_xt = dref.q_sample(x0.double(), logsnr.double()[:, None, None, None], eps.double())
+    close(xt_nchw, ref_xt, None, floor=1e-6, name="q_sample")
+    assert torch.equal(from_nhwc(xt, Cc), xt_nchw.cpu()) and (xt[..., 3] == 0).all()
+    od = nhwc(out, ldo)
+    loss, aux = torch.empty(n, device=DEV), torch.empty(n, 2, device=DEV)
+    H.loss_fwd(x0.to(DEV), eps.to(DEV), xt, 4, od, ldo, logsnr.to(DEV), H.OUT_TYPES[mot], H.REWEIGHTS[rw], loss, aux, n, Cc, R * R)
+    close(loss, loss64.detach(), loss32, floor=1e-5, name="loss")
+    dout = torch.full((n, R, R, ldo), 5.0, device=DEV)
+    H.loss_bwd(x0.to(DEV), eps.to(DEV), xt, 4, od, ldo, logsnr.to(DEV), aux, gl.to(DEV), H.OUT_TYPES[mot], H.REWEIGHTS[rw], dout,
+               ldo, ldo, n, Cc, R * R)
+    close(from_nhwc(dout, Co), o64.grad, None, floor=2e-5, name="dloss")
+    assert (dout[..., Co:] == 0).all()
+
+
+def test_sumsq_adamw_ema(H):
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2) * 0.1
+    pd, gd = torch.zeros(n + 1, device=DEV)[:n], g.to(DEV)
+    pd.copy_(p)
+    ss = torch.empty(1, device=DEV)
+    H.sumsq(gd, ss)
+    close(ss, (g.double() ** 2).sum().reshape(1), None, floor=1e-6, name="sumsq")
+    ref = torch.nn.Parameter(p.clone().double())
+    ref.grad = g.clone().double()
+    opt = torch.optim.AdamW([ref], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    ema_ref = p.clone().double()
+    m, v, ema = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), p.clone().to(DEV)
+    for step in range(1, 4):
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        ema_ref += (1 - 0.99) * (ref.detach() - ema_ref)
+        ref.grad = g.clone().double()
+        H.sumsq(gd, ss)
+        H.adamw_ema(pd, gd, m, v, ema, ss, 1.0, 2e-4, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, 0.99)
+    close(pd, ref.detach(), None, floor=2e-6, name="adamw p")
+    close(ema, ema_ref, None, floor=2e-6, name="ema")

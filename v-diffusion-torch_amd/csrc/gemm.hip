@@ -1,0 +1,492 @@
+// gemm.hip -- the fp32 MFMA tile engine behind every matmul-shaped op of the hot path:
+//   * 3x3 convolution forward / input-gradient (implicit GEMM, A = NHWC patches)   reference modules.py:141-144
+//   * 3x3 convolution weight-gradient (implicit GEMM over pixels, split-K slabs)    autograd of the same
+//   * 1x1 convolution / linear / attention contractions and their gradients         unet.py:57-63,70-71,134; modules.py:79-80
+//
+// Design (gfx950 / CDNA4):
+//   - v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD.  A workgroup is 4 waves
+//     (one per SIMD), each owning a (BM/2)x(BN/2) sub-tile as 32x32 accumulator blocks.
+//   - K is consumed in tiles of 32.  Tiles are staged global -> registers -> LDS (so transforms / zero padding
+//     can be applied on the way) and double buffered: the global loads of tile t+1 are in flight while tile t
+//     feeds the matrix cores; one barrier per K tile.
+//   - operands that are k-contiguous in memory live in LDS as [row][32] with the 16-byte chunk index XOR-swizzled
+//     by (row>>1)&7, read back with one conflict-free ds_read_b128 per 4 MFMAs (lane (i,h) takes k = 8s+4h+j,
+//     j = 0..3: the MFMA's own k order is a free permutation as long as A and B agree); operands that are
+//     row-contiguous live as [32][rows] and are read with ds_read_b32 (lanes = consecutive rows).
+//   - all edges are predicated (rows, columns, k, image borders, channel padding), so ragged shapes need no padding
+//     beyond 4-float alignment of the contiguous dimension.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 32;   // K tile
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias; const float* R;
+    int M, N, K;
+    long long lda, ldb, ldc, ldr;
+    int nh;
+    long long sAb, sAh, sBb, sBh, sCb, sCh, sRb, sRh;
+    float alpha; int accumulate;
+    int H, W, Cin;
+    int kt_total, kt_per_split;
+    long long slab_stride;
+};
+
+__device__ __forceinline__ int row_swz(int row, int chunk) { return row * KT + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int BM, int BN, int AK, int BK, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * KT];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * KT;
+
+    constexpr int MT = BM / 64, NT = BN / 64;          // 32x32 blocks per wave in m / n
+    constexpr int AIT = BM / 32, BIT = BN / 32;        // float4 staged per thread
+    constexpr int A_CPR = BM / 4, A_RPP = 256 / A_CPR; // COL-layout tile: chunks per k-row, k-rows per pass
+    constexpr int B_CPR = BN / 4, B_RPP = 256 / B_CPR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int m0 = blockIdx.y * BM;
+    int n0 = blockIdx.x * BN;
+    int tapN = 0, ci0 = 0;
+    if (BK == VD_IM2COL) {
+        const int cchN = (p.Cin + BN - 1) / BN;
+        tapN = blockIdx.x / cchN;
+        ci0 = (blockIdx.x % cchN) * BN;
+        n0 = tapN * p.Cin + ci0;
+    }
+    const float* A = p.A;
+    const float* B = p.B;
+    float* C = p.C;
+    const float* R = p.R;
+    int kt_begin = 0, kt_end = p.kt_total;
+    if (SPLITK) {
+        kt_begin = blockIdx.z * p.kt_per_split;
+        kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
+        C += (long long)blockIdx.z * p.slab_stride;
+    } else {
+        const int zb = blockIdx.z / p.nh, zh = blockIdx.z % p.nh;
+        A += zb * p.sAb + zh * p.sAh;
+        B += zb * p.sBb + zh * p.sBh;
+        C += zb * p.sCb + zh * p.sCh;
+        if (R) R += zb * p.sRb + zh * p.sRh;
+    }
+
+    // ---- per-thread staging coordinates
+    const int r_row = tid >> 3, r_chunk = tid & 7;       // ROW-layout: row = r_row + 32*it, 16-byte chunk r_chunk
+    int ay[AIT], ax[AIT];                                // image coordinates of the A rows (IM2COL A)
+    if (AK == VD_IM2COL) {
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int m = m0 + r_row + 32 * it;
+            const int rem = m % (p.H * p.W);
+            ay[it] = rem / p.W;
+            ax[it] = rem % p.W;
+        }
+    }
+    const int cchA = (AK == VD_IM2COL) ? (p.Cin + KT - 1) / KT : 1;
+
+    f32x4 ra[AIT], rb[BIT];
+
+    auto load_tiles = [&](int kt) {
+        // ---------------- A
+        if (AK == VD_ROW || AK == VD_IM2COL) {
+            int kbase, kwidth, dy = 0, dx = 0;
+            if (AK == VD_IM2COL) {
+                const int tap = kt / cchA, c0 = (kt % cchA) * KT;
+                dy = tap / 3 - 1; dx = tap % 3 - 1;
+                kbase = c0; kwidth = p.Cin - c0;
+            } else { kbase = kt * KT; kwidth = p.K - kbase; }
+            const int ck = r_chunk * 4;
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                const int m = m0 + r_row + 32 * it;
+                bool ok = (m < p.M) && (ck < kwidth);
+                long long off;
+                if (AK == VD_IM2COL) {
+                    ok = ok && ((unsigned)(ay[it] + dy) < (unsigned)p.H) && ((unsigned)(ax[it] + dx) < (unsigned)p.W);
+                    off = ((long long)m + dy * p.W + dx) * p.lda + kbase + ck;
+                } else off = (long long)m * p.lda + kbase + ck;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4*>(A + off);
+                ra[it] = v;
+            }
+        } else {   // VD_COL: A stored [k][m]
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                const int kk = tid / A_CPR + it * A_RPP, cm = (tid % A_CPR) * 4;
+                const int k = kt * KT + kk;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < p.K && m0 + cm < p.M) v = *reinterpret_cast<const f32x4*>(A + (long long)k * p.lda + m0 + cm);
+                ra[it] = v;
+            }
+        }
+        // ---------------- B
+        if (BK == VD_ROW) {
+            int kbase, kwidth;
+            if (AK == VD_IM2COL) {
+                const int tap = kt / cchA, c0 = (kt % cchA) * KT;
+                kbase = tap * p.Cin + c0; kwidth = p.Cin - c0;
+            } else { kbase = kt * KT; kwidth = p.K - kbase; }
+            const int ck = r_chunk * 4;
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int n = n0 + r_row + 32 * it;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < p.N && ck < kwidth) v = *reinterpret_cast<const f32x4*>(B + (long long)n * p.ldb + kbase + ck);
+                rb[it] = v;
+            }
+        } else if (BK == VD_COL) {
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int kk = tid / B_CPR + it * B_RPP, cn = (tid % B_CPR) * 4;
+                const int k = kt * KT + kk;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < p.K && n0 + cn < p.N) v = *reinterpret_cast<const f32x4*>(B + (long long)k * p.ldb + n0 + cn);
+                rb[it] = v;
+            }
+        } else {   // VD_IM2COL B (wgrad): k = pixel, n = (tapN, ci0 + cn)
+            const int dy = tapN / 3 - 1, dx = tapN % 3 - 1;
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int kk = tid / B_CPR + it * B_RPP, cn = (tid % B_CPR) * 4;
+                const int k = kt * KT + kk;
+                const int rem = k % (p.H * p.W);
+                const int yy = rem / p.W + dy, xx = rem % p.W + dx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < p.K && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && ci0 + cn < p.Cin)
+                    v = *reinterpret_cast<const f32x4*>(B + ((long long)k + dy * p.W + dx) * p.ldb + ci0 + cn);
+                rb[it] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* as = As + buf * BM * KT;
+        float* bs = Bs + buf * BN * KT;
+        if (AK == VD_COL) {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                const int kk = tid / A_CPR + it * A_RPP, cm = (tid % A_CPR) * 4;
+                *reinterpret_cast<f32x4*>(as + kk * BM + cm) = ra[it];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it)
+                *reinterpret_cast<f32x4*>(as + row_swz(r_row + 32 * it, r_chunk)) = ra[it];
+        }
+        if (BK == VD_ROW) {
+#pragma unroll
+            for (int it = 0; it < BIT; ++it)
+                *reinterpret_cast<f32x4*>(bs + row_swz(r_row + 32 * it, r_chunk)) = rb[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int kk = tid / B_CPR + it * B_RPP, cn = (tid % B_CPR) * 4;
+                *reinterpret_cast<f32x4*>(bs + kk * BN + cn) = rb[it];
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* as = As + buf * BM * KT;
+        const float* bs = Bs + buf * BN * KT;
+#pragma unroll
+        for (int s = 0; s < KT / 8; ++s) {
+            f32x4 fa[MT], fb[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = wm + 32 * a + li;
+                if (AK == VD_COL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
+                } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz(row, 2 * s + lh));
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int row = wn + 32 * b + li;
+                if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz(row, 2 * s + lh));
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[b][j] = bs[(8 * s + 4 * lh + j) * BN + row];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: one barrier per K tile
+    if (kt_begin < kt_end) {
+        load_tiles(kt_begin);
+        store_tiles(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool more = kt + 1 < kt_end;
+            if (more) load_tiles(kt + 1);
+            compute(buf);
+            if (more) store_tiles(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue: D[row][col], col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int ncol = wn + 32 * b + li;
+        const int n = n0 + ncol;
+        const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
+        if (!nok) continue;
+        const float bv = (!SPLITK && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[a][b][r];
+                if (!SPLITK) {
+                    v = v * p.alpha + bv;
+                    if (R) v += R[(long long)m * p.ldr + n];
+                    if (p.accumulate) v += C[(long long)m * p.ldc + n];
+                }
+                C[(long long)m * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// out (+)= sum over slabs; optional OIHW transposition for the conv weight gradient
+__global__ void reduce_slabs_kernel(const float* slabs, int S, long long slab_stride, int M, int N, float* out,
+                                    long long ldo, int accumulate, float alpha) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[z * slab_stride + idx];
+    const int m = idx / N, n = idx % N;
+    float* o = out + (long long)m * ldo + n;
+    s *= alpha;
+    *o = accumulate ? *o + s : s;
+}
+
+__global__ void reduce_slabs_oihw_kernel(const float* slabs, int S, long long slab_stride, int Cout, int Cin,
+                                         int Cout_w, int Cin_w, float* dw, int accumulate) {
+    // slab element (co, tap*Cin + ci) -> dw[(co*Cin_w + ci)*9 + tap]
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Cout * 9 * Cin;
+    if (idx >= total) return;
+    const int co = idx / (9 * Cin), rem = idx % (9 * Cin);
+    const int tap = rem / Cin, ci = rem % Cin;
+    if (co >= Cout_w || ci >= Cin_w) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[z * slab_stride + idx];
+    float* o = dw + ((long long)co * Cin_w + ci) * 9 + tap;
+    *o = accumulate ? *o + s : s;
+}
+
+__global__ void pack_conv3x3_kernel(const float* w, int Cout_w, int Cin_w, float* wf, int Cin_p, float* wd, int Cout_p) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wf) {   // wf[co][tap][ci_p]
+        const long long tot = (long long)Cout_w * 9 * Cin_p;
+        if (idx < tot) {
+            const int co = idx / (9 * Cin_p), rem = idx % (9 * Cin_p);
+            const int tap = rem / Cin_p, ci = rem % Cin_p;
+            wf[idx] = (ci < Cin_w) ? w[((long long)co * Cin_w + ci) * 9 + tap] : 0.f;
+        }
+    }
+    if (wd) {   // wd[ci][tap][co_p] = w[co][ci][8 - tap]
+        const long long tot = (long long)Cin_w * 9 * Cout_p;
+        if (idx < tot) {
+            const int ci = idx / (9 * Cout_p), rem = idx % (9 * Cout_p);
+            const int tap = rem / Cout_p, co = rem % Cout_p;
+            wd[idx] = (co < Cout_w) ? w[((long long)co * Cin_w + ci) * 9 + (8 - tap)] : 0.f;
+        }
+    }
+}
+
+template <int BM, int BN, int AK, int BK, bool SPLITK>
+void launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
+}
+
+template <int AK, int BK>
+void launch_tile(int tile, bool splitk, const GemmArgs& a, dim3 grid, hipStream_t st) {
+    if (tile == 128) { if (splitk) launch<128, 128, AK, BK, true>(a, grid, st); else launch<128, 128, AK, BK, false>(a, grid, st); }
+    else             { if (splitk) launch<64, 64, AK, BK, true>(a, grid, st);   else launch<64, 64, AK, BK, false>(a, grid, st); }
+}
+
+int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
+    VD_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "vd_gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
+    VD_REQUIRE(d.A && d.B && d.C, "vd_gemm: null operand");
+    VD_REQUIRE(vd_aligned16(d.A) && vd_aligned16(d.B), "vd_gemm: A/B must be 16-byte aligned");
+    VD_REQUIRE(d.lda % 4 == 0 && d.ldb % 4 == 0, "vd_gemm: lda/ldb must be multiples of 4 floats (lda=%lld ldb=%lld)",
+               (long long)d.lda, (long long)d.ldb);
+    const int ak = d.a_kind, bk = d.b_kind;
+    const bool conv = (ak == VD_IM2COL), wgrad = (bk == VD_IM2COL);
+    VD_REQUIRE(!(conv && bk != VD_ROW), "vd_gemm: IM2COL A needs ROW B");
+    VD_REQUIRE(!(wgrad && ak != VD_COL), "vd_gemm: IM2COL B needs COL A");
+    if (ak == VD_ROW) VD_REQUIRE(d.K % 4 == 0, "vd_gemm: K %% 4 != 0 for k-contiguous A (K=%d)", d.K);
+    if (ak == VD_COL) VD_REQUIRE(d.M % 4 == 0, "vd_gemm: M %% 4 != 0 for m-contiguous A (M=%d)", d.M);
+    if (bk == VD_COL) VD_REQUIRE(d.N % 4 == 0, "vd_gemm: N %% 4 != 0 for n-contiguous B (N=%d)", d.N);
+    if (conv || wgrad) VD_REQUIRE(d.Cin % 4 == 0 && d.H > 0 && d.W > 0, "vd_gemm: bad image geometry");
+    const int batch = d.batch > 0 ? d.batch : 1;
+    const int splitk = d.splitk > 1 ? d.splitk : 1;
+    VD_REQUIRE(!(splitk > 1 && batch > 1), "vd_gemm: split-K and batch are exclusive");
+
+    GemmArgs a;
+    a.A = d.A; a.B = d.B; a.C = d.C; a.bias = d.bias; a.R = d.R;
+    a.M = d.M; a.N = d.N; a.K = d.K;
+    a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr;
+    a.nh = d.nh > 0 ? d.nh : 1;
+    a.sAb = d.sAb; a.sAh = d.sAh; a.sBb = d.sBb; a.sBh = d.sBh; a.sCb = d.sCb; a.sCh = d.sCh; a.sRb = d.sRb; a.sRh = d.sRh;
+    a.alpha = d.alpha; a.accumulate = d.accumulate;
+    a.H = d.H; a.W = d.W; a.Cin = d.Cin;
+    a.kt_total = conv ? 9 * ((d.Cin + KT - 1) / KT) : (d.K + KT - 1) / KT;
+    a.kt_per_split = a.kt_total; a.slab_stride = 0;
+
+    // tile choice: 128x128 when that still gives >= 1.5 blocks per CU, else 64x64
+    auto ntiles = [&](int t) {
+        long long nm = (d.M + t - 1) / t;
+        long long nn = wgrad ? 9LL * ((d.Cin + t - 1) / t) : (d.N + t - 1) / t;
+        return nm * nn;
+    };
+    int tile = d.tile;
+    if (tile != 128 && tile != 64) tile = (ntiles(128) * batch * splitk >= 384 && d.N > 64 && d.M > 64) ? 128 : 64;
+    const long long nm = (d.M + tile - 1) / tile;
+    const long long nn = wgrad ? 9LL * ((d.Cin + tile - 1) / tile) : (d.N + tile - 1) / tile;
+    VD_REQUIRE(nm <= 65535, "vd_gemm: too many row tiles (%lld)", nm);
+
+    float* final_C = d.C;
+    if (splitk > 1) {
+        a.kt_per_split = (a.kt_total + splitk - 1) / splitk;
+        const int used = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;
+        a.slab_stride = (long long)d.M * d.N;
+        VD_REQUIRE(d.ws && d.ws_bytes >= (int64_t)(used * a.slab_stride * 4), "vd_gemm: split-K workspace too small");
+        a.C = d.ws; a.ldc = d.N;
+        dim3 grid(nn, nm, used);
+        if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, true, a, grid, st);
+        else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, true, a, grid, st);
+        else if (ak == VD_ROW && bk == VD_ROW) launch_tile<VD_ROW, VD_ROW>(tile, true, a, grid, st);
+        else if (ak == VD_ROW && bk == VD_COL) launch_tile<VD_ROW, VD_COL>(tile, true, a, grid, st);
+        else VD_REQUIRE(false, "vd_gemm: split-K not built for kinds (%d,%d)", ak, bk);
+        VD_LAUNCH_CHECK("gemm_kernel(splitk)");
+        if (!wgrad) {   // plain reduce here; the conv wgrad caller reduces with the OIHW transposition itself
+            const long long tot = (long long)d.M * d.N;
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, d.ws, used, a.slab_stride,
+                               d.M, d.N, final_C, d.ldc, d.accumulate, d.alpha);
+            VD_LAUNCH_CHECK("reduce_slabs_kernel");
+        }
+        return 0;
+    }
+    dim3 grid(nn, nm, batch);
+    if (ak == VD_ROW && bk == VD_ROW) launch_tile<VD_ROW, VD_ROW>(tile, false, a, grid, st);
+    else if (ak == VD_ROW && bk == VD_COL) launch_tile<VD_ROW, VD_COL>(tile, false, a, grid, st);
+    else if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, false, a, grid, st);
+    else if (ak == VD_COL && bk == VD_ROW) launch_tile<VD_COL, VD_ROW>(tile, false, a, grid, st);
+    else if (ak == VD_IM2COL && bk == VD_ROW) launch_tile<VD_IM2COL, VD_ROW>(tile, false, a, grid, st);
+    else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, false, a, grid, st);
+    else VD_REQUIRE(false, "vd_gemm: unsupported operand kinds (%d,%d)", ak, bk);
+    VD_LAUNCH_CHECK("gemm_kernel");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vd_gemm(const vd_gemm_desc* d, void* stream) {
+    VD_REQUIRE(d != nullptr, "vd_gemm: null descriptor");
+    return run_gemm(*d, (hipStream_t)stream);
+}
+
+extern "C" int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, const float* bias, const float* res,
+                          int64_t ldres, float* y, int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t Cin,
+                          int32_t Cout, int32_t accumulate, void* stream) {
+    VD_REQUIRE(Cin % 4 == 0, "vd_conv3x3: Cin must be a multiple of 4 (got %d)", Cin);
+    vd_gemm_desc d = {};
+    d.A = xin; d.B = wpack; d.C = y; d.bias = bias; d.R = res;
+    d.M = nimg * H * W; d.N = Cout; d.K = 9 * Cin;
+    d.a_kind = VD_IM2COL; d.b_kind = VD_ROW;
+    d.lda = ldx; d.ldb = 9LL * Cin; d.ldc = ldy; d.ldr = ldres;
+    d.batch = 1; d.nh = 1; d.alpha = 1.f; d.accumulate = accumulate;
+    d.H = H; d.W = W; d.Cin = Cin;
+    return run_gemm(d, (hipStream_t)stream);
+}
+
+static int wgrad_split(int nimg, int H, int W, int Cin, int Cout) {
+    const long long kt = ((long long)nimg * H * W + KT - 1) / KT;
+    const int tile = 128;
+    const long long tiles = ((Cout + tile - 1) / tile) * 9LL * ((Cin + tile - 1) / tile);
+    long long s = (768 + tiles - 1) / tiles;          // aim at ~3 blocks per CU
+    if (s > kt / 8) s = kt / 8;                        // keep >= 8 K tiles per slab
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+extern "C" size_t vd_conv3x3_wgrad_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    return (size_t)wgrad_split(nimg, H, W, Cin, Cout) * Cout * 9 * Cin * sizeof(float);
+}
+
+extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
+                                int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, int32_t Cin_w, int32_t Cout_w,
+                                int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VD_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "vd_conv3x3_wgrad: Cin/Cout must be multiples of 4 (%d,%d)", Cin, Cout);
+    VD_REQUIRE(Cin_w <= Cin && Cout_w <= Cout, "vd_conv3x3_wgrad: real dims exceed padded dims");
+    const int S = wgrad_split(nimg, H, W, Cin, Cout);
+    VD_REQUIRE(ws && ws_bytes >= (size_t)S * Cout * 9 * Cin * 4, "vd_conv3x3_wgrad: workspace too small");
+    vd_gemm_desc d = {};
+    d.A = dy; d.B = xin; d.C = ws;
+    d.M = Cout; d.N = 9 * Cin; d.K = nimg * H * W;
+    d.a_kind = VD_COL; d.b_kind = VD_IM2COL;
+    d.lda = lddy; d.ldb = ldx; d.ldc = 9LL * Cin;
+    d.batch = 1; d.nh = 1; d.alpha = 1.f;
+    d.H = H; d.W = W; d.Cin = Cin;
+    d.splitk = S; d.ws = ws; d.ws_bytes = (int64_t)ws_bytes; d.tile = 128;
+    const long long slab = (long long)Cout * 9 * Cin;
+    int used = S;
+    if (S > 1) {
+        int rc = run_gemm(d, st);
+        if (rc) return rc;
+        const long long kt = ((long long)d.K + KT - 1) / KT, per = (kt + S - 1) / S;
+        used = (int)((kt + per - 1) / per);
+    } else {
+        d.splitk = 1;
+        int rc = run_gemm(d, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(reduce_slabs_oihw_kernel, dim3((slab + 255) / 256), dim3(256), 0, st, ws, used, slab, Cout, Cin,
+                       Cout_w, Cin_w, dw_oihw, accumulate);
+    VD_LAUNCH_CHECK("reduce_slabs_oihw_kernel");
+    return 0;
+}
+
+extern "C" int vd_pack_conv3x3(const float* w_oihw, int32_t Cout_w, int32_t Cin_w, float* wf, int32_t Cin_p, float* wd,
+                               int32_t Cout_p, void* stream) {
+    VD_REQUIRE(w_oihw && (wf || wd), "vd_pack_conv3x3: null pointer");
+    VD_REQUIRE((!wf || Cin_p >= Cin_w) && (!wd || Cout_p >= Cout_w), "vd_pack_conv3x3: padded dims too small");
+    long long tot = 0;
+    if (wf) tot = (long long)Cout_w * 9 * Cin_p;
+    if (wd && (long long)Cin_w * 9 * Cout_p > tot) tot = (long long)Cin_w * 9 * Cout_p;
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout_w,
+                       Cin_w, wf, Cin_p, wd, Cout_p);
+    VD_LAUNCH_CHECK("pack_conv3x3_kernel");
+    return 0;
+}

@@ -1,0 +1,423 @@
+// norm.hip -- GroupNorm(32,C) + SiLU + FiLM + dropout + 2x resample, forward and backward, NHWC.
+// Reference call sites: nn.GroupNorm unet.py:28-30 (<- :52,119,123,230), nn.SiLU :25, FiLM :145-146,
+// nn.Dropout :135,147, nn.AvgPool2d/nn.Upsample :127-132, and their autograd backward.
+//
+// These kernels are HBM-bound.  Work split:
+//   chan_reduce  : per-(image, pixel-chunk, channel) partial sums, float4 over channels so every wave reads
+//                  whole contiguous NHWC rows; thread-private accumulators, deterministic LDS tree, no atomics
+//   finalize     : tiny kernels turning partials into per-(image,group) statistics / per-(image,channel) tables
+//   apply        : float4 elementwise pass reading x once (+ an L1/L2-resident coefficient table)
+#include "common.h"
+
+namespace {
+
+constexpr int PPC = 128;     // pixels per reduction chunk
+
+struct ReduceArgs {
+    const float* x; long long ldx;        // MODE 0/2: data ; MODE 1: forward input of the norm
+    const float* dy; long long lddy;      // MODE 1: upstream gradient (output resolution)
+    const float* coef;                    // MODE 1: [nimg][4][C]
+    int act; float p_drop; unsigned long long seed; int resample; int has_norm;
+    int H, W;                             // input resolution (MODE 1)
+    long long HW;                         // pixels per image (rows for MODE 2)
+    int C, nimg, chunks;
+    float* part;                          // [nimg][chunks][2][C]
+};
+
+// gradient wrt the pre-activation z of one float4 of the forward input
+__device__ __forceinline__ f32x4 dz_of(const ReduceArgs& p, const float* dy_img, int y, int x, int c4, f32x4 xv, f32x4 sc,
+                                       f32x4 of, unsigned long long vec_index) {
+    f32x4 g;
+    if (p.resample == VD_RS_NONE) {
+        g = *reinterpret_cast<const f32x4*>(dy_img + ((long long)y * p.W + x) * p.lddy + c4);
+    } else if (p.resample == VD_RS_DOWN) {
+        const int Wo = p.W >> 1;
+        g = *reinterpret_cast<const f32x4*>(dy_img + ((long long)(y >> 1) * Wo + (x >> 1)) * p.lddy + c4) * 0.25f;
+    } else {
+        const int Wo = p.W << 1;
+        const float* b0 = dy_img + ((long long)(2 * y) * Wo + 2 * x) * p.lddy + c4;
+        g = *reinterpret_cast<const f32x4*>(b0) + *reinterpret_cast<const f32x4*>(b0 + p.lddy) +
+            *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy) + *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy + p.lddy);
+    }
+    if (p.p_drop > 0.f) g *= vd_dropout_scale4(p.seed, vec_index, p.p_drop);
+    if (p.act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = xv[j] * sc[j] + of[j];
+            const float s = vd_sigmoid(z);
+            g[j] *= s * (1.f + z * (1.f - s));
+        }
+    }
+    return g;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const ReduceArgs p, int Cb) {
+    __shared__ float red[256][8];
+    const int chunk = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * Cb;
+    const int cb = min(Cb, p.C - c0);
+    const int vecs = cb >> 2, rows = 256 / vecs;
+    const int tid = threadIdx.x, r = tid / vecs, v = tid % vecs;
+    const int c4 = c0 + 4 * v;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const long long pix0 = (long long)chunk * PPC;
+    const int np = (int)min((long long)PPC, p.HW - pix0);
+    if (r < rows) {
+        const float* ximg = p.x + (long long)b * p.HW * p.ldx;
+        if (MODE == 1) {
+            const float* cf = p.coef + (long long)b * 4 * p.C;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f}, nr = sc, nm = of;
+            if (p.has_norm) {
+                sc = *reinterpret_cast<const f32x4*>(cf + c4);
+                of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
+                nr = *reinterpret_cast<const f32x4*>(cf + 2 * p.C + c4);
+                nm = *reinterpret_cast<const f32x4*>(cf + 3 * p.C + c4);
+            }
+            const long long HWo = p.resample == VD_RS_DOWN ? p.HW / 4 : (p.resample == VD_RS_UP ? p.HW * 4 : p.HW);
+            const float* dimg = p.dy + (long long)b * HWo * p.lddy;
+            for (int i = r; i < np; i += rows) {
+                const long long pix = pix0 + i;
+                const int y = (int)(pix / p.W), x = (int)(pix % p.W);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(ximg + pix * p.ldx + c4);
+                const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * (p.C >> 2) + (c4 >> 2);
+                const f32x4 dz = dz_of(p, dimg, y, x, c4, xv, sc, of, vi);
+                a0 += dz;
+                a1 += dz * (xv * nr + nm);
+            }
+        } else {
+            for (int i = r; i < np; i += rows) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(ximg + (pix0 + i) * p.ldx + c4);
+                a0 += xv;
+                if (MODE == 0) a1 += xv * xv;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid][j] = a0[j]; red[tid][4 + j] = a1[j]; }
+    __syncthreads();
+    if (tid < vecs) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        for (int q = 0; q < rows; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0[j] += red[q * vecs + tid][j]; s1[j] += red[q * vecs + tid][4 + j]; }
+        }
+        float* o = p.part + ((long long)(b * p.chunks + chunk) * 2) * p.C + c4;
+        *reinterpret_cast<f32x4*>(o) = s0;
+        *reinterpret_cast<f32x4*>(o + p.C) = s1;
+    }
+}
+
+__global__ void gn_stats_finalize_kernel(const float* part, int nimg, int chunks, int C, int G, long long HW, float eps,
+                                         float* stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nimg * G) return;
+    const int b = idx / G, g = idx % G, cg = C / G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const float* q = part + ((long long)(b * chunks + ch) * 2) * C + g * cg;
+        for (int c = 0; c < cg; ++c) { s1 += (double)q[c]; s2 += (double)q[C + c]; }
+    }
+    const double n = (double)cg * (double)HW;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * idx] = (float)mean;
+    stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// coef[b][0][c] = rstd*gamma*(1+scale)   coef[b][1][c] = (beta - mean*rstd*gamma)*(1+scale) + shift
+// coef[b][2][c] = rstd                   coef[b][3][c] = -mean*rstd
+__global__ void gn_coef_kernel(const float* stats, const float* gamma, const float* beta, const float* film, int nimg,
+                               int C, int G, float* coef) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nimg * C) return;
+    const int b = idx / C, c = idx % C, g = c / (C / G);
+    const float mean = stats[2 * (b * G + g)], rstd = stats[2 * (b * G + g) + 1];
+    float sc = rstd * gamma[c];
+    float of = beta[c] - mean * sc;
+    if (film) {
+        const float shift = film[(long long)b * 2 * C + c], scale = film[(long long)b * 2 * C + C + c];
+        sc *= (1.f + scale);
+        of = of * (1.f + scale) + shift;
+    }
+    float* o = coef + (long long)b * 4 * C + c;
+    o[0] = sc; o[C] = of; o[2 * C] = rstd; o[3 * C] = -mean * rstd;
+}
+
+struct ApplyArgs {
+    const float* x; long long ldx; const float* coef; int has_norm; int act; float p_drop; unsigned long long seed;
+    int resample; float* y; long long ldy; int nimg, H, W, C;
+};
+
+__device__ __forceinline__ f32x4 fwd_one(const ApplyArgs& p, const float* ximg, long long pix, int c4, f32x4 sc, f32x4 of,
+                                         int b) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(ximg + pix * p.ldx + c4);
+    if (p.has_norm) v = v * sc + of;
+    if (p.act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * vd_sigmoid(v[j]);
+    }
+    if (p.p_drop > 0.f) {
+        const unsigned long long vi = ((unsigned long long)b * p.H * p.W + pix) * (p.C >> 2) + (c4 >> 2);
+        v *= vd_dropout_scale4(p.seed, vi, p.p_drop);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const ApplyArgs p) {
+    const int vecs = p.C >> 2;
+    const int Ho = p.resample == VD_RS_DOWN ? p.H >> 1 : (p.resample == VD_RS_UP ? p.H << 1 : p.H);
+    const int Wo = p.resample == VD_RS_DOWN ? p.W >> 1 : (p.resample == VD_RS_UP ? p.W << 1 : p.W);
+    const long long per_img = (long long)Ho * Wo * vecs, total = per_img * p.nimg;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / per_img);
+        const long long rem = idx % per_img;
+        const long long po = rem / vecs;
+        const int c4 = (int)(rem % vecs) * 4;
+        const int yo = (int)(po / Wo), xo = (int)(po % Wo);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f};
+        if (p.has_norm) {
+            const float* cf = p.coef + (long long)b * 4 * p.C;
+            sc = *reinterpret_cast<const f32x4*>(cf + c4);
+            of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
+        }
+        const float* ximg = p.x + (long long)b * p.H * p.W * p.ldx;
+        f32x4 out;
+        if (p.resample == VD_RS_NONE) out = fwd_one(p, ximg, po, c4, sc, of, b);
+        else if (p.resample == VD_RS_UP) out = fwd_one(p, ximg, (long long)(yo >> 1) * p.W + (xo >> 1), c4, sc, of, b);
+        else {
+            const long long q = (long long)(2 * yo) * p.W + 2 * xo;
+            out = (fwd_one(p, ximg, q, c4, sc, of, b) + fwd_one(p, ximg, q + 1, c4, sc, of, b) +
+                   fwd_one(p, ximg, q + p.W, c4, sc, of, b) + fwd_one(p, ximg, q + p.W + 1, c4, sc, of, b)) * 0.25f;
+        }
+        *reinterpret_cast<f32x4*>(p.y + ((long long)b * Ho * Wo + po) * p.ldy + c4) = out;
+    }
+}
+
+// ---------------------------------------------------------------- backward finalize: one block per image
+// in : part [chunks][2][C] partial sums of dz and dz*xhat
+// out: q [b][3][C] = {rstd*k, rstd*m1, rstd*m2};  dfilm[b][2C];  pgb [b][2][C] per-image dgamma/dbeta terms
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* part, int chunks, const float* coef,
+                                                              const float* gamma, const float* beta, const float* film,
+                                                              int C, int G, long long HW, float* q, float* dfilm,
+                                                              float* pgb) {
+    extern __shared__ float sh[];      // [2][C] k*S1, k*S2 ; then [2][G]
+    float* k1 = sh; float* k2 = sh + C; float* gm = sh + 2 * C;
+    const int b = blockIdx.x, cg = C / G;
+    const float* cf = coef + (long long)b * 4 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const float* pp = part + ((long long)(b * chunks + ch) * 2) * C;
+            s1 += pp[c]; s2 += pp[C + c];
+        }
+        float fs = 1.f;
+        if (film) {
+            fs = 1.f + film[(long long)b * 2 * C + C + c];
+            dfilm[(long long)b * 2 * C + c] = s1;                                   // d shift
+            dfilm[(long long)b * 2 * C + C + c] = gamma[c] * s2 + beta[c] * s1;     // d scale = sum dz * (gamma*xhat + beta)
+        }
+        const float k = gamma[c] * fs;
+        k1[c] = k * s1; k2[c] = k * s2;
+        pgb[((long long)b * 2) * C + c] = fs * s2;          // dgamma term
+        pgb[((long long)b * 2 + 1) * C + c] = fs * s1;      // dbeta term
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float m1 = 0.f, m2 = 0.f;
+        for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { m1 += k1[c]; m2 += k2[c]; }
+        const float inv = 1.f / ((float)cg * (float)HW);
+        gm[threadIdx.x] = m1 * inv; gm[G + threadIdx.x] = m2 * inv;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        const float rstd = cf[2 * C + c];
+        const float fs = film ? 1.f + film[(long long)b * 2 * C + C + c] : 1.f;
+        float* qq = q + (long long)b * 3 * C + c;
+        qq[0] = rstd * gamma[c] * fs; qq[C] = rstd * gm[g]; qq[2 * C] = rstd * gm[G + g];
+    }
+}
+
+// out[c] (+)= sum_b in[b][c]   (two planes at once: dgamma, dbeta)
+__global__ void sum_over_images_kernel(const float* pgb, int nimg, int C, float* dgamma, float* dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, bsum = 0.f;
+    for (int b = 0; b < nimg; ++b) { a += pgb[((long long)b * 2) * C + c]; bsum += pgb[((long long)b * 2 + 1) * C + c]; }
+    dgamma[c] = accumulate ? dgamma[c] + a : a;
+    dbeta[c] = accumulate ? dbeta[c] + bsum : bsum;
+}
+
+struct BwdApplyArgs {
+    ReduceArgs r; const float* q; const float* add; long long ldadd; float* dx; long long lddx; int accumulate_dx;
+};
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const BwdApplyArgs a) {
+    const ReduceArgs& p = a.r;
+    const int vecs = p.C >> 2;
+    const long long per_img = p.HW * vecs, total = per_img * p.nimg;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / per_img);
+        const long long rem = idx % per_img;
+        const long long pix = rem / vecs;
+        const int c4 = (int)(rem % vecs) * 4;
+        const int y = (int)(pix / p.W), x = (int)(pix % p.W);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f}, nr = sc, nm = of;
+        if (p.has_norm) {
+            const float* cf = p.coef + (long long)b * 4 * p.C;
+            sc = *reinterpret_cast<const f32x4*>(cf + c4);
+            of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
+            nr = *reinterpret_cast<const f32x4*>(cf + 2 * p.C + c4);
+            nm = *reinterpret_cast<const f32x4*>(cf + 3 * p.C + c4);
+        }
+        const long long HWo = p.resample == VD_RS_DOWN ? p.HW / 4 : (p.resample == VD_RS_UP ? p.HW * 4 : p.HW);
+        const float* dimg = p.dy + (long long)b * HWo * p.lddy;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (p.has_norm) xv = *reinterpret_cast<const f32x4*>(p.x + ((long long)b * p.HW + pix) * p.ldx + c4);
+        const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vecs + (c4 >> 2);
+        f32x4 d = dz_of(p, dimg, y, x, c4, xv, sc, of, vi);
+        if (p.has_norm) {
+            const float* qq = a.q + (long long)b * 3 * p.C;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qq + c4);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qq + p.C + c4);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(qq + 2 * p.C + c4);
+            d = q0 * d - q1 - (xv * nr + nm) * q2;
+        }
+        if (a.add) d += *reinterpret_cast<const f32x4*>(a.add + ((long long)b * p.HW + pix) * a.ldadd + c4);
+        float* o = a.dx + ((long long)b * p.HW + pix) * a.lddx + c4;
+        if (a.accumulate_dx) d += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = d;
+    }
+}
+
+__global__ void colsum_finalize_kernel(const float* part, int chunks, int N, float* out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) s += part[(long long)ch * 2 * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+inline int pick_cb(int C) {           // channels handled by one reduction block (<= 1024, multiple of 4)
+    int split = 1;
+    while (split < C && (C % split != 0 || C / split > 1024 || (C / split) % 4 != 0)) ++split;
+    return C / split;
+}
+
+inline int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    if (g > 256LL * 16) g = 256LL * 16;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" size_t vd_gn_ws_bytes(int32_t nimg, int32_t HW, int32_t C) {
+    const long long chunks = (HW + PPC - 1) / PPC;
+    // partials + q table + per-image dgamma/dbeta terms
+    return (size_t)(nimg * chunks * 2LL * C + (long long)nimg * 3 * C + (long long)nimg * 2 * C) * sizeof(float);
+}
+
+extern "C" int vd_gn_stats(const float* x, int64_t ldx, int32_t nimg, int32_t HW, int32_t C, int32_t G, float eps,
+                           float* stats, float* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VD_REQUIRE(C % 4 == 0 && C % G == 0 && ldx % 4 == 0, "vd_gn_stats: C=%d G=%d ldx=%lld unsupported", C, G, (long long)ldx);
+    VD_REQUIRE(ws_bytes >= vd_gn_ws_bytes(nimg, HW, C), "vd_gn_stats: workspace too small");
+    const int Cb = pick_cb(C);
+    VD_REQUIRE(C % Cb == 0 && Cb % 4 == 0 && Cb <= 1024, "vd_gn_stats: cannot split C=%d", C);
+    ReduceArgs p = {};
+    p.x = x; p.ldx = ldx; p.HW = HW; p.C = C; p.nimg = nimg; p.chunks = (HW + PPC - 1) / PPC; p.part = ws;
+    hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(p.chunks, nimg, C / Cb), dim3(256), 0, st, p, Cb);
+    VD_LAUNCH_CHECK("chan_reduce_kernel<0>");
+    hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((nimg * G + 127) / 128), dim3(128), 0, st, ws, nimg, p.chunks, C, G,
+                       (long long)HW, eps, stats);
+    VD_LAUNCH_CHECK("gn_stats_finalize_kernel");
+    return 0;
+}
+
+extern "C" int vd_gn_apply(const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                           const float* film, int32_t act, float p_drop, uint64_t seed, int32_t resample, float* y,
+                           int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* coef,
+                           void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "vd_gn_apply: C/ld must be multiples of 4");
+    VD_REQUIRE(resample != VD_RS_DOWN || (H % 2 == 0 && W % 2 == 0), "vd_gn_apply: odd size cannot be average-pooled");
+    const int has_norm = gamma != nullptr;
+    if (has_norm) {
+        VD_REQUIRE(stats && beta && coef && C % G == 0, "vd_gn_apply: missing norm operands");
+        hipLaunchKernelGGL(gn_coef_kernel, dim3((nimg * C + 255) / 256), dim3(256), 0, st, stats, gamma, beta, film, nimg, C,
+                           G, coef);
+        VD_LAUNCH_CHECK("gn_coef_kernel");
+    }
+    ApplyArgs p = {x, ldx, coef, has_norm, act, p_drop, seed, resample, y, ldy, nimg, H, W, C};
+    const long long Ho = resample == VD_RS_DOWN ? H / 2 : (resample == VD_RS_UP ? H * 2 : H);
+    const long long Wo = resample == VD_RS_DOWN ? W / 2 : (resample == VD_RS_UP ? W * 2 : W);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(Ho * Wo * (C / 4) * nimg)), dim3(256), 0, st, p);
+    VD_LAUNCH_CHECK("gn_apply_kernel");
+    return 0;
+}
+
+extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef,
+                               const float* gamma, const float* beta, const float* film, int32_t act, float p_drop,
+                               uint64_t seed, int32_t resample, const float* add, int64_t ldadd, float* dx, int64_t lddx,
+                               int32_t accumulate_dx, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate_params,
+                               int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* ws, size_t ws_bytes,
+                               void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VD_REQUIRE(C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "vd_gn_apply_bwd: C/ld must be multiples of 4");
+    const int has_norm = gamma != nullptr;
+    const long long HW = (long long)H * W;
+    BwdApplyArgs a = {};
+    ReduceArgs& p = a.r;
+    p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy; p.coef = coef; p.act = act; p.p_drop = p_drop; p.seed = seed;
+    p.resample = resample; p.has_norm = has_norm; p.H = H; p.W = W; p.HW = HW; p.C = C; p.nimg = nimg;
+    p.chunks = (int)((HW + PPC - 1) / PPC);
+    a.add = add; a.ldadd = ldadd; a.dx = dx; a.lddx = lddx; a.accumulate_dx = accumulate_dx;
+    if (has_norm) {
+        VD_REQUIRE(x && coef && beta && dgamma && dbeta && C % G == 0 && ldx % 4 == 0, "vd_gn_apply_bwd: missing norm operands");
+        VD_REQUIRE(!film || dfilm, "vd_gn_apply_bwd: film given without dfilm");
+        VD_REQUIRE(ws && ws_bytes >= vd_gn_ws_bytes(nimg, (int)HW, C), "vd_gn_apply_bwd: workspace too small");
+        const int Cb = pick_cb(C);
+        VD_REQUIRE(C % Cb == 0 && Cb % 4 == 0 && Cb <= 1024, "vd_gn_apply_bwd: cannot split C=%d", C);
+        float* part = ws;
+        float* q = part + (long long)nimg * p.chunks * 2 * C;
+        float* pgb = q + (long long)nimg * 3 * C;
+        p.part = part;
+        hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(p.chunks, nimg, C / Cb), dim3(256), 0, st, p, Cb);
+        VD_LAUNCH_CHECK("chan_reduce_kernel<1>");
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nimg), dim3(256), (2 * C + 2 * G) * sizeof(float), st, part, p.chunks,
+                           coef, gamma, beta, film, C, G, HW, q, dfilm, pgb);
+        VD_LAUNCH_CHECK("gn_bwd_finalize_kernel");
+        hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 127) / 128), dim3(128), 0, st, pgb, nimg, C, dgamma, dbeta,
+                           accumulate_params);
+        VD_LAUNCH_CHECK("sum_over_images_kernel");
+        a.q = q;
+    }
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(HW * (C / 4) * nimg)), dim3(256), 0, st, a);
+    VD_LAUNCH_CHECK("gn_bwd_apply_kernel");
+    return 0;
+}
+
+extern "C" size_t vd_colsum_ws_bytes(int64_t M, int32_t N) {
+    return (size_t)(((M + PPC - 1) / PPC) * 2 * N) * sizeof(float);
+}
+
+extern "C" int vd_colsum(const float* x, int64_t ldx, int64_t M, int32_t N, float* out, int32_t accumulate, float* ws,
+                         size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VD_REQUIRE(N % 4 == 0 && ldx % 4 == 0, "vd_colsum: N/ld must be multiples of 4 (N=%d)", N);
+    VD_REQUIRE(ws && ws_bytes >= vd_colsum_ws_bytes(M, N), "vd_colsum: workspace too small");
+    const int Cb = pick_cb(N);
+    VD_REQUIRE(N % Cb == 0 && Cb % 4 == 0 && Cb <= 1024, "vd_colsum: cannot split N=%d", N);
+    ReduceArgs p = {};
+    p.x = x; p.ldx = ldx; p.HW = M; p.C = N; p.nimg = 1; p.chunks = (int)((M + PPC - 1) / PPC); p.part = ws;
+    VD_REQUIRE(p.chunks <= 65535 * 32, "vd_colsum: too many rows");
+    hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(p.chunks, 1, N / Cb), dim3(256), 0, st, p, Cb);
+    VD_LAUNCH_CHECK("chan_reduce_kernel<2>");
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, st, ws, p.chunks, N, out, accumulate);
+    VD_LAUNCH_CHECK("colsum_finalize_kernel");
+    return 0;
+}

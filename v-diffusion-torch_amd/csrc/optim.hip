@@ -1,0 +1,76 @@
+// optim.hip -- optimizer tail as multi-tensor passes over FLAT fp32 buffers:
+// global-norm clip (nn.utils.clip_grad_norm_, train_utils.py:161) + AdamW (train.py:158) + EMA (utils.py:144-149)
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long long n, float* part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void sumsq_final_kernel(const float* part, int nb, float* out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) s += (double)part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = (float)sh[0];
+}
+
+__global__ void adamw_ema_kernel(float* p, const float* g, float* m, float* v, float* ema, long long n, const float* gnorm_sq,
+                                 float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                 float ema_decay) {
+    float clip = 1.f;
+    if (gnorm_sq && max_norm > 0.f) {
+        const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);          // torch clip_grad_norm_
+        clip = c < 1.f ? c : 1.f;
+    }
+    const float step = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        pi -= step * mi / (sqrtf(vi) * rs2 + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (ema) ema[i] += (1.f - ema_decay) * (pi - ema[i]);
+    }
+}
+
+constexpr int SUMSQ_BLOCKS = 1024;
+}  // namespace
+
+extern "C" size_t vd_sumsq_ws_bytes(int64_t) { return SUMSQ_BLOCKS * sizeof(float); }
+
+extern "C" int vd_sumsq(const float* g, int64_t n, float* out1, float* ws, size_t ws_bytes, void* stream) {
+    VD_REQUIRE(ws && ws_bytes >= SUMSQ_BLOCKS * sizeof(float), "vd_sumsq: workspace too small");
+    VD_REQUIRE(vd_aligned16(g), "vd_sumsq: buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, (long long)n, ws);
+    VD_LAUNCH_CHECK("sumsq_partial_kernel");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, SUMSQ_BLOCKS, out1);
+    VD_LAUNCH_CHECK("sumsq_final_kernel");
+    return 0;
+}
+
+extern "C" int vd_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gnorm_sq,
+                            float max_norm, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                            float ema_decay, void* stream) {
+    long long grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (long long)n,
+                       gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay);
+    VD_LAUNCH_CHECK("adamw_ema_kernel");
+    return 0;
+}

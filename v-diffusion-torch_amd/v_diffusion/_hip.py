@@ -1,0 +1,262 @@
+"""ctypes binding of libvdiff_hip.so (C ABI: include/vdiff_hip.h).
+
+PyTorch is used only for device memory and streams: every function here takes torch CUDA(HIP) tensors,
+passes raw pointers + the current stream to the HIP library and returns nothing the library allocated.
+There is NO fallback: a missing library, a CPU tensor or a non-zero return code raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvdiff_hip.so")
+
+ROW, COL, IM2COL = 0, 1, 2
+RS_NONE, RS_DOWN, RS_UP = 0, 1, 2
+OUT_TYPES = {"v": 0, "x0": 1, "eps": 2, "both": 3}
+REWEIGHTS = {"constant": 0, "snr": 1, "snr_trunc": 2, "snr_1plus": 3}
+
+_i32, _i64, _f32, _f64, _u64, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64, C.c_void_p, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("R", _vp),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("a_kind", _i32), ("b_kind", _i32),
+                ("lda", _i64), ("ldb", _i64), ("ldc", _i64), ("ldr", _i64),
+                ("batch", _i32), ("nh", _i32),
+                ("sAb", _i64), ("sAh", _i64), ("sBb", _i64), ("sBh", _i64),
+                ("sCb", _i64), ("sCh", _i64), ("sRb", _i64), ("sRh", _i64),
+                ("alpha", _f32), ("accumulate", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32),
+                ("splitk", _i32), ("ws", _vp), ("ws_bytes", _i64), ("tile", _i32)]
+
+
+_SIGNATURES = {
+    "vd_version": (C.c_int, []),
+    "vd_last_error": (C.c_char_p, []),
+    "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_pack_conv3x3": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "vd_gn_ws_bytes": (_sz, [_i32, _i32, _i32]),
+    "vd_gn_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "vd_gn_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vd_gn_apply_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _vp, _i64, _i32,
+                                  _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_colsum_ws_bytes": (_sz, [_i64, _i32]),
+    "vd_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "vd_axpby": (C.c_int, [_vp, _i64, _f32, _vp, _i64, _f32, _i64, _i32, _vp]),
+    "vd_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "vd_silu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "vd_softmax_rows": (C.c_int, [_vp, _i64, _i32, _vp]),
+    "vd_softmax_rows_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
+    "vd_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
+    "vd_nhwc_to_nchw": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vd_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _vp]),
+    "vd_class_embed": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_class_embed_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vd_multitag_norm": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "vd_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
+    "vd_loss_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "vd_sample_step": (C.c_int, [_vp, _i64, _vp, _i64, _vp, C.POINTER(_f32), _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp,
+                                 _i32, _i32, _i32, _vp]),
+    "vd_sumsq_ws_bytes": (_sz, [_i64]),
+    "vd_sumsq": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "vd_adamw_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (raises if it has not been built -- there is no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (or make -C v-diffusion-torch_amd/csrc). "
+                "The v_diffusion hot path has no CPU/PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)           # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipError(f"{what} failed (rc={rc}): {lib().vd_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("v_diffusion HIP op received a CPU tensor: the hot path runs on an MI355X only (no CPU fallback)")
+    if t.dtype not in (torch.float32, torch.float64):
+        raise HipError(f"unsupported dtype {t.dtype}")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Per-(device, stream, tag) scratch buffer, grown on demand.  Kernels on one stream are ordered, so a scratch
+    region can be reused by the next launch on the same stream."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(int(nbytes), 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------------------------- wrappers
+def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None, R=None, ldr=0, batch=1, nh=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), alpha=1.0, accumulate=False, splitk=1, tile=0):
+    d = GemmDesc()
+    d.A, d.B, d.C, d.bias, d.R = ptr(A), ptr(B), ptr(Cm), ptr(bias), ptr(R)
+    d.M, d.N, d.K, d.a_kind, d.b_kind = M, N, K, a_kind, b_kind
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.batch, d.nh = batch, nh
+    (d.sAb, d.sAh), (d.sBb, d.sBh), (d.sCb, d.sCh), (d.sRb, d.sRh) = sA, sB, sC, sR
+    d.alpha, d.accumulate = alpha, int(accumulate)
+    d.splitk, d.tile = splitk, tile
+    if splitk > 1:
+        ws = workspace(splitk * M * N * 4, A.device, "splitk")
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
+
+
+def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False):
+    _check(lib().vd_conv3x3(ptr(x), ldx, ptr(wpack), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
+                            int(accumulate), stream()), "vd_conv3x3")
+
+
+def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False):
+    nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
+    ws = workspace(nb, x.device, "wgrad")
+    _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), Cin_w, Cout_w,
+                                  int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
+
+
+def pack_conv3x3(w, Cout_w, Cin_w, wf=None, Cin_p=0, wd=None, Cout_p=0):
+    _check(lib().vd_pack_conv3x3(ptr(w), Cout_w, Cin_w, ptr(wf), Cin_p, ptr(wd), Cout_p, stream()), "vd_pack_conv3x3")
+
+
+def gn_stats(x, ldx, nimg, HW, Cc, stats, G=32, eps=1e-6):
+    nb = lib().vd_gn_ws_bytes(nimg, HW, Cc)
+    ws = workspace(nb, x.device, "gn")
+    _check(lib().vd_gn_stats(ptr(x), ldx, nimg, HW, Cc, G, eps, ptr(stats), ws.data_ptr(), ws.numel() * 4, stream()),
+           "vd_gn_stats")
+
+
+def gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G=32):
+    _check(lib().vd_gn_apply(ptr(x), ldx, ptr(stats), ptr(gamma), ptr(beta), ptr(film), int(act), float(p_drop), int(seed),
+                             resample, ptr(y), ldy, nimg, H, W, Cc, G, ptr(coef), stream()), "vd_gn_apply")
+
+
+def gn_apply_bwd(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
+                 accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G=32):
+    nb = lib().vd_gn_ws_bytes(nimg, H * W, Cc)
+    ws = workspace(nb, dy.device, "gn")
+    _check(lib().vd_gn_apply_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(coef), ptr(gamma), ptr(beta), ptr(film), int(act),
+                                 float(p_drop), int(seed), resample, ptr(add), ldadd, ptr(dx), lddx, int(accumulate_dx),
+                                 ptr(dfilm), ptr(dgamma), ptr(dbeta), int(accumulate_params), nimg, H, W, Cc, G,
+                                 ws.data_ptr(), ws.numel() * 4, stream()), "vd_gn_apply_bwd")
+
+
+def colsum(x, ldx, M, N, out, accumulate=False):
+    nb = lib().vd_colsum_ws_bytes(M, N)
+    ws = workspace(nb, x.device, "colsum")
+    _check(lib().vd_colsum(ptr(x), ldx, M, N, ptr(out), int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_colsum")
+
+
+def axpby(x, ldx, alpha, y, ldy, beta, rows, Cc):
+    _check(lib().vd_axpby(ptr(x), ldx, alpha, ptr(y), ldy, beta, rows, Cc, stream()), "vd_axpby")
+
+
+def silu(x, y):
+    _check(lib().vd_silu(ptr(x), ptr(y), x.numel(), stream()), "vd_silu")
+
+
+def silu_bwd(x, dy, dx, accumulate=False):
+    _check(lib().vd_silu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), int(accumulate), stream()), "vd_silu_bwd")
+
+
+def softmax_rows(s, rows, L):
+    _check(lib().vd_softmax_rows(ptr(s), rows, L, stream()), "vd_softmax_rows")
+
+
+def softmax_rows_bwd(p, dp, rows, L, alpha):
+    _check(lib().vd_softmax_rows_bwd(ptr(p), ptr(dp), rows, L, alpha, stream()), "vd_softmax_rows_bwd")
+
+
+def nchw_to_nhwc(x, y, nimg, Cc, H, W, ldy):
+    _check(lib().vd_nchw_to_nhwc(ptr(x), ptr(y), nimg, Cc, H, W, ldy, stream()), "vd_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(x, ldx, y, nimg, Cc, H, W):
+    _check(lib().vd_nhwc_to_nchw(ptr(x), ldx, ptr(y), nimg, Cc, H, W, stream()), "vd_nhwc_to_nchw")
+
+
+def timestep_embedding(t, out, n, dim, scale=1000.0):
+    if t.dtype != torch.float64:
+        raise HipError("timestep_embedding expects fp64 timesteps")
+    _check(lib().vd_timestep_embedding(ptr(t), ptr(out), n, dim, scale, stream()), "vd_timestep_embedding")
+
+
+def class_embed(y, w, bias, temb, n, emb, ncls):
+    _check(lib().vd_class_embed(ptr(y), ptr(w), ptr(bias), ptr(temb), n, emb, ncls, stream()), "vd_class_embed")
+
+
+def class_embed_bwd(y, dtemb, dw, dbias, n, emb, ncls, accumulate=False):
+    _check(lib().vd_class_embed_bwd(ptr(y), ptr(dtemb), ptr(dw), ptr(dbias), n, emb, ncls, int(accumulate), stream()),
+           "vd_class_embed_bwd")
+
+
+def multitag_norm(y, out, n, ncls):
+    _check(lib().vd_multitag_norm(ptr(y), ptr(out), n, ncls, stream()), "vd_multitag_norm")
+
+
+def q_sample(x0, eps, logsnr, xt, ld, xt_nchw, n, Cc, HW):
+    _check(lib().vd_q_sample(ptr(x0), ptr(eps), ptr(logsnr), ptr(xt), ld, ptr(xt_nchw), n, Cc, HW, stream()), "vd_q_sample")
+
+
+def loss_fwd(x0, eps, xt, ldxt, out, ldo, logsnr, mot, rw, loss, aux, n, Cc, HW):
+    _check(lib().vd_loss_fwd(ptr(x0), ptr(eps), ptr(xt), ldxt, ptr(out), ldo, ptr(logsnr), mot, rw, ptr(loss), ptr(aux),
+                             n, Cc, HW, stream()), "vd_loss_fwd")
+
+
+def loss_bwd(x0, eps, xt, ldxt, out, ldo, logsnr, aux, gloss, mot, rw, dout, lddo, ldpad, n, Cc, HW):
+    _check(lib().vd_loss_bwd(ptr(x0), ptr(eps), ptr(xt), ldxt, ptr(out), ldo, ptr(logsnr), ptr(aux), ptr(gloss), mot, rw,
+                             ptr(dout), lddo, ldpad, n, Cc, HW, stream()), "vd_loss_bwd")
+
+
+def sample_step(xt, ldx, out, ldo, noise, k8, mot, cfg, last, clip, xn, ldn, dup, xn_nchw, n, Cc, HW):
+    arr = (_f32 * 8)(*[float(v) for v in k8])
+    _check(lib().vd_sample_step(ptr(xt), ldx, ptr(out), ldo, ptr(noise), arr, mot, int(cfg), int(last), int(clip), ptr(xn),
+                                ldn, int(dup), ptr(xn_nchw), n, Cc, HW, stream()), "vd_sample_step")
+
+
+def sumsq(g, out1):
+    ws = workspace(lib().vd_sumsq_ws_bytes(g.numel()), g.device, "sumsq")
+    _check(lib().vd_sumsq(ptr(g), g.numel(), ptr(out1), ws.data_ptr(), ws.numel() * 4, stream()), "vd_sumsq")
+
+
+def adamw_ema(p, g, m, v, ema, gnorm_sq, max_norm, lr, b1, b2, eps, wd, bc1, bc2, ema_decay):
+    _check(lib().vd_adamw_ema(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), ptr(gnorm_sq), max_norm, lr, b1, b2, eps,
+                              wd, bc1, bc2, ema_decay, stream()), "vd_adamw_ema")
