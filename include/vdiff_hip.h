@@ -141,27 +141,27 @@ int vd_class_embed_bwd(const float* y, const float* dtemb, float* dw, float* dbi
 int vd_multitag_norm(const float* y, float* out, int32_t n, int32_t ncls, void* stream);
 
 /* ------------------------------------------------------------------ diffusion process (diffusion.py)
+ * All images NCHW (the reference call surface); the UNet converts to NHWC at its own boundary.
  * model_out_type: 0 = v, 1 = x0, 2 = eps, 3 = both ; reweight: 0 = constant, 1 = snr, 2 = snr_trunc, 3 = snr_1plus */
-/* q_sample (diffusion.py:242-245): xt_nhwc[b,y,x,0..C) = sqrt(sigmoid(l_b)) x0 + sqrt(sigmoid(-l_b)) eps, NCHW in, NHWC(ld) out */
-int vd_q_sample(const float* x0_nchw, const float* eps_nchw, const float* logsnr, float* xt_nhwc, int64_t ld,
-                float* xt_nchw_opt, int32_t n, int32_t C, int32_t HW, void* stream);
-/* train_loss mse branch (diffusion.py:520-541): per-sample loss[n]; aux[n][2] keeps the two branch means */
-int vd_loss_fwd(const float* x0_nchw, const float* eps_nchw, const float* xt_nhwc, int64_t ldxt,
-                const float* out_nhwc, int64_t ldo, const float* logsnr,
+/* q_sample (diffusion.py:242-245): xt = sqrt(sigmoid(l_b)) x0 + sqrt(sigmoid(-l_b)) eps */
+int vd_q_sample(const float* x0, const float* eps, const float* logsnr, float* xt, int32_t n, int32_t C, int32_t HW, void* stream);
+/* train_loss mse branch (diffusion.py:520-541 with the conversions of :466-490): per-sample loss[n];
+ * aux[n][2] keeps the two branch means of snr_trunc (x0-mse, eps-mse) for the backward pass.
+ * out has C channels (2C for model_out_type "both"). */
+int vd_loss_fwd(const float* x0, const float* eps, const float* xt, const float* out, const float* logsnr,
                 int32_t model_out_type, int32_t reweight, float* loss, float* aux, int32_t n, int32_t C, int32_t HW, void* stream);
-/* d loss / d model_out, scaled by gloss[n]; written NHWC (ld) with padding channels zeroed */
-int vd_loss_bwd(const float* x0_nchw, const float* eps_nchw, const float* xt_nhwc, int64_t ldxt,
-                const float* out_nhwc, int64_t ldo, const float* logsnr, const float* aux, const float* gloss,
-                int32_t model_out_type, int32_t reweight, float* dout_nhwc, int64_t lddo, int32_t ldpad,
+/* dout = gloss[b] * d loss_b / d out */
+int vd_loss_bwd(const float* x0, const float* eps, const float* xt, const float* out, const float* logsnr,
+                const float* aux, const float* gloss, int32_t model_out_type, int32_t reweight, float* dout,
                 int32_t n, int32_t C, int32_t HW, void* stream);
-/* one reverse step (p_mean_var + CFG + noise, diffusion.py:317-392) for a whole batch that shares the step index.
- * out_nhwc has `rows = n * (1 + cfg)` images (cond/uncond interleaved when cfg).  k: 8 host-computed floats
- * {alpha_t, sigma_t, aux_t0, aux_t1, c1, c2, noise_scale, w_guide}; see diffusion.py in the host package.
- * Writes the new state as NHWC (ld) for the next UNet call, duplicated/interleaved when cfg_next_dup. */
-int vd_sample_step(const float* xt_nhwc, int64_t ldx, const float* out_nhwc, int64_t ldo, const float* noise_nchw,
-                   const float* k, int32_t model_out_type, int32_t cfg, int32_t last_step, int32_t clip,
-                   float* xnext_nhwc, int64_t ldn, int32_t dup_next, float* xnext_nchw_opt,
-                   int32_t n, int32_t C, int32_t HW, void* stream);
+/* one reverse step (p_mean_var + CFG + noise, diffusion.py:317-392) for a batch that shares the step index.
+ * out has n*(1+cfg) images, cond/uncond interleaved when cfg (diffusion.py:369-372).
+ * k: 8 HOST floats {a0, b0x, b0e, c1, c2, noise_scale, w_guide, 0}:  x0_hat = clip(a0*xt + b0x*out (+ b0e*out_eps)),
+ * mean = last_step ? x0_hat : c1*xt + c2*x0_hat, guided = mean_c + w (mean_c - mean_u), xn = guided + noise_scale*noise.
+ * xdup (optional): the new state duplicated to 2n interleaved images = the next CFG UNet input. */
+int vd_sample_step(const float* xt, const float* out, const float* noise, const float* k,
+                   int32_t model_out_type, int32_t cfg, int32_t last_step, int32_t clip,
+                   float* xn, float* xdup, int32_t n, int32_t C, int32_t HW, void* stream);
 
 /* ------------------------------------------------------------------ optimizer tail (train_utils.py:159-168, utils.py:144-149)
  * sum of squares of a flat buffer (global-norm clip), fused clip + AdamW + EMA over flat fp32 buffers */

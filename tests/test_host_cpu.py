@@ -1,0 +1,152 @@
+"""CPU-side checks of the host package: C ABI export table, state_dict contract, engine plan, host schedule math.
+No compute kernels are launched here (there is no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from v_diffusion import _hip
+    hdr = open(os.path.join(ROOT, "include", "vdiff_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(vd_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(_hip.EXPORTS), "binding table and header disagree"
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.fail(f"{_hip.LIB_PATH} missing: run __graft_entry__.build()")
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+    lib.vd_version.restype = ctypes.c_int
+    assert lib.vd_version() == 100
+
+
+def test_gemm_desc_layout_matches_header(tmp_path):
+    """the ctypes mirror of vd_gemm_desc has the layout gcc gives the C struct"""
+    import subprocess
+    from v_diffusion._hip import GemmDesc
+    fields = [f[0] for f in GemmDesc._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "vdiff_hip.h"\nint main(){printf("%zu", sizeof(vd_gemm_desc));' + \
+        "".join(f'printf(" %zu", offsetof(vd_gemm_desc, {f}));' for f in fields) + "return 0;}"
+    src = tmp_path / "layout.c"
+    src.write_text(prog)
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    nums = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert nums[0] == ctypes.sizeof(GemmDesc)
+    assert nums[1:] == [getattr(GemmDesc, f).offset for f in fields]
+
+
+@pytest.mark.parametrize("cfgname", ["CIFAR_COND", "CIFAR_UNCOND", "CELEBA"])
+def test_state_dict_contract_cpu(golden_dir, cfgname):
+    from oracle import cases
+    from oracle.unet_ref import param_shapes
+    import v_diffusion
+    cfg = getattr(cases, cfgname)
+    m = v_diffusion.UNet(**cfg)
+    shapes = param_shapes(cfg)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s in shapes.items()]
+    if cfgname != "CIFAR_UNCOND":
+        g = np.load(os.path.join(golden_dir, "unet_cifar10_cond.npz" if cfgname == "CIFAR_COND" else "unet_celeba.npz"))
+        assert [str(n) for n in g["grad_names"]] == [k for k, _ in m.named_parameters()]      # reference parameters() order
+
+
+def test_engine_plan_concat_wiring():
+    from oracle import cases
+    import v_diffusion
+    from v_diffusion.engine import UNetEngine
+    for cfg in (cases.CIFAR_COND, cases.CELEBA, cases.TINY["tinyB"]["cfg"]):
+        m = v_diffusion.UNet(**cfg)
+        e = UNetEngine(m)
+        nrb, L = cfg["num_res_blocks"], len(cfg["ch_multipliers"])
+        assert len(e.pushes) == 1 + L * nrb + (L - 1)                       # reference: every down output is pushed
+        assert sum(b.consumes for b in e.plan) == len(e.pushes)             # and popped exactly once
+        for k, (_, cs, consumer, ch) in enumerate(e.pushes):
+            assert e.plan[consumer].cin == ch + cs
+        # pops are LIFO
+        order = [b.src_hs for b in e.plan if b.consumes]
+        assert order == sorted(order, reverse=True)
+
+
+def test_lecun_init_statistics():
+    from v_diffusion.modules import Conv2d, Linear
+    torch.manual_seed(0)
+    c = Conv2d(64, 128, 3, 1, 1)
+    std = c.weight.std().item()
+    # truncated normal at +-2 sigma has std 0.8796; reference applies no variance correction (modules.py:25-35)
+    assert abs(std - 0.8796 / (64 * 9) ** 0.5) < 0.01 / (64 * 9) ** 0.5 * 3
+    assert float(c.bias.abs().max()) == 0 and float(c.weight.abs().max()) <= 2.0 / (64 * 9) ** 0.5 + 1e-6
+    assert float(Linear(8, 8, init_scale=0.).weight.abs().max()) == 0
+
+
+def test_host_schedule_and_posteriors_vs_golden(golden_dir):
+    import v_diffusion
+    from v_diffusion.diffusion import logsnr_to_posterior, logsnr_to_posterior_ddim
+    g = np.load(os.path.join(golden_dir, "tables.npz"))
+    for sched in ("cosine", "linear", "sigmoid", "legacy"):
+        f = v_diffusion.get_logsnr_schedule(sched, -20.0, 20.0)
+        for T in (8, 50, 250):
+            grid = torch.arange(T + 1, dtype=torch.float64) / T
+            if sched == "linear":
+                grid = grid.clamp(1e-6, 1 - 1e-6)
+            np.testing.assert_allclose(f(grid).numpy(), g[f"logsnr_{sched}_{T}"], rtol=1e-12, atol=1e-9)
+    for T in (8, 50, 250):
+        l = torch.from_numpy(g[f"logsnr_cosine_{T}"])
+        ls, lt = l[:-1].float(), l[1:].float()
+        c1, c2, lv = logsnr_to_posterior_ddim(ls, lt, 0.0)
+        np.testing.assert_allclose(np.stack([c1.numpy(), c2.numpy()]), g[f"ddim_{T}"], rtol=1e-6)
+        assert float(lv) == -np.inf
+        for vt, frac in (("fixed_large", None), ("fixed_small", None), ("fixed_medium", 0.3)):
+            c1, c2, lv = logsnr_to_posterior(ls, lt, vt, frac)
+            np.testing.assert_allclose(np.stack([c1.numpy(), c2.numpy(), lv.numpy()]), g[f"ddpm_{vt}_{T}"], rtol=1e-6)
+    # DDIM(eta=1) == DDPM fixed_small (reference self-check diffusion.py:594-614)
+    a = logsnr_to_posterior_ddim(ls, lt, 1.0)
+    b = logsnr_to_posterior(ls, lt, "fixed_small")
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_step_coefficients_match_reference_tables(golden_dir):
+    import v_diffusion
+    g = np.load(os.path.join(golden_dir, "tables.npz"))
+    T = 50
+    gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine"), T, "v", "fixed_medium", "snr_trunc", "mse",
+                                       intp_frac=0.3, w_guide=1.0)
+    for step in (0, 1, 25, 49):
+        k = gd._step_coefs(step, use_ddim=True)
+        np.testing.assert_allclose(k[3:5], g["ddim_50"][:, step], rtol=1e-6)
+        assert k[5] == 0.0 and k[6] == 1.0
+        k = gd._step_coefs(step, use_ddim=False)
+        np.testing.assert_allclose(k[3:5], g["ddpm_fixed_medium_50"][:2, step], rtol=1e-6)
+        if step > 0:
+            np.testing.assert_allclose(k[5], np.exp(0.5 * g["ddpm_fixed_medium_50"][2, step]), rtol=1e-5)
+        lt = np.float32(g["logsnr_cosine_50"][step + 1])
+        np.testing.assert_allclose(k[0], np.sqrt(1 / (1 + np.exp(-np.float64(lt)))), rtol=1e-6)
+
+
+def test_cpu_tensors_fail_loudly():
+    import v_diffusion
+    from oracle.cases import TINY, make_inputs
+    case = TINY["tinyC"]
+    m = v_diffusion.UNet(**case["cfg"])
+    x, t, y = make_inputs(case["cfg"], 2, case["R"], case["label"])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(x, t, y)
+    gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine"), 8, "v", "fixed_large", "snr_trunc", "mse")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gd.train_loss(m, x, t, y)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gd.p_sample(m, (2, 3, 8, 8), device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "v-diffusion-torch_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"

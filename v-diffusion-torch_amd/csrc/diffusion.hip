@@ -2,7 +2,7 @@
 //   q_sample                         reference v_diffusion/diffusion.py:242-245
 //   train_loss (mse) forward/backward  diffusion.py:466-490,520-541 ; flat_mean functions.py:102-104
 //   one reverse step (p_mean_var + CFG + noise)  diffusion.py:317-392
-// Images enter NCHW (the reference call surface) and leave NHWC with padded channels (what the conv engine reads).
+// All images here are NCHW, the layout of the reference call surface; the UNet converts at its own boundary.
 #include "common.h"
 
 namespace {
@@ -28,23 +28,14 @@ __device__ __forceinline__ PredCoef pred_coef(int type, float l) {
     return k;
 }
 
-__global__ void q_sample_kernel(const float* x0, const float* eps, const float* logsnr, float* xt, long long ld,
-                                float* xt_nchw, int n, int C, long long HW) {
-    const long long total = (long long)n * HW;
+__global__ void q_sample_kernel(const float* x0, const float* eps, const float* logsnr, float* xt, long long n,
+                                long long CHW) {
+    const long long total = n * CHW;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const long long b = idx / HW, pix = idx % HW;
-        const float l = logsnr[b];
+        const float l = logsnr[idx / CHW];
         const float sa = sqrtf(1.f / (1.f + expf(-l))), ss = sqrtf(1.f / (1.f + expf(l)));
-        for (int c = 0; c < (int)ld; ++c) {
-            float v = 0.f;
-            if (c < C) {
-                const long long s = (b * C + c) * HW + pix;
-                v = x0[s] * sa + eps[s] * ss;
-                if (xt_nchw) xt_nchw[s] = v;
-            }
-            xt[idx * ld + c] = v;
-        }
+        xt[idx] = x0[idx] * sa + eps[idx] * ss;
     }
 }
 
@@ -61,7 +52,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 }
 
 struct LossArgs {
-    const float* x0; const float* eps; const float* xt; long long ldxt; const float* out; long long ldo;
+    const float* x0; const float* eps; const float* xt; const float* out;     // NCHW; out has C or 2C channels
     const float* logsnr; int type, rw; int n, C; long long HW;
 };
 
@@ -74,21 +65,21 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const LossArgs p, float* 
     const float sa = sqrtf(1.f / (1.f + expf(-l))), ss = sqrtf(1.f / (1.f + expf(l)));
     float e0 = 0.f, e1 = 0.f;
     const long long N = (long long)p.C * p.HW;
+    const int Co = p.type == OUT_BOTH ? 2 * p.C : p.C;
+    const float* ob = p.out + (long long)b * Co * p.HW;
     for (long long i = threadIdx.x; i < N; i += blockDim.x) {
-        const int c = (int)(i / p.HW);
-        const long long pix = i % p.HW;
         const float x0 = p.x0[(long long)b * N + i], ep = p.eps[(long long)b * N + i];
-        const float* o = p.out + ((long long)b * p.HW + pix) * p.ldo;
+        const float o = ob[i];
         if (p.rw == RW_SNR_TRUNC) {
-            const float xt = p.xt[((long long)b * p.HW + pix) * p.ldxt + c];
-            const float oe = p.type == OUT_BOTH ? o[p.C + c] : 0.f;
-            const float x0h = k.a0 * xt + k.b0x * o[c] + k.b0e * oe;
-            const float eph = k.a1 * xt + k.b1x * o[c] + k.b1e * oe;
+            const float xt = p.xt[(long long)b * N + i];
+            const float oe = p.type == OUT_BOTH ? ob[N + i] : 0.f;
+            const float x0h = k.a0 * xt + k.b0x * o + k.b0e * oe;
+            const float eph = k.a1 * xt + k.b1x * o + k.b1e * oe;
             e0 += (x0 - x0h) * (x0 - x0h);
             e1 += (ep - eph) * (ep - eph);
         } else {
             const float tgt = p.rw == RW_CONSTANT ? x0 : (p.rw == RW_SNR ? ep : (-x0 * ss + ep * sa));
-            e0 += (tgt - o[c]) * (tgt - o[c]);
+            e0 += (tgt - o) * (tgt - o);
         }
     }
     e0 = block_sum(e0, sh);
@@ -100,73 +91,60 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const LossArgs p, float* 
     }
 }
 
-__global__ void loss_bwd_kernel(const LossArgs p, const float* aux, const float* gloss, float* dout, long long lddo,
-                                int ldpad) {
-    const long long total = (long long)p.n * p.HW;
-    const long long N = (long long)p.C * p.HW;
+__global__ void loss_bwd_kernel(const LossArgs p, const float* aux, const float* gloss, float* dout) {
+    const long long N = (long long)p.C * p.HW, total = (long long)p.n * N;
+    const int Co = p.type == OUT_BOTH ? 2 * p.C : p.C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const long long b = idx / p.HW, pix = idx % p.HW;
+        const long long b = idx / N, i = idx % N;
         const float l = p.logsnr[b];
         const PredCoef k = pred_coef(p.type, l);
         const float sa = sqrtf(1.f / (1.f + expf(-l))), ss = sqrtf(1.f / (1.f + expf(l)));
         const float g = gloss[b] * 2.f / (float)N;
-        const float* o = p.out + idx * p.ldo;
-        float* d = dout + idx * lddo;
-        const int sel = aux[2 * b] >= aux[2 * b + 1] ? 0 : 1;
-        for (int c = 0; c < p.C; ++c) {
-            const long long s = (b * p.C + c) * p.HW + pix;
-            const float x0 = p.x0[s], ep = p.eps[s];
-            if (p.rw == RW_SNR_TRUNC) {
-                const float xt = p.xt[idx * p.ldxt + c];
-                const float oe = p.type == OUT_BOTH ? o[p.C + c] : 0.f;
-                float r, bx, be;
-                if (sel == 0) { r = (k.a0 * xt + k.b0x * o[c] + k.b0e * oe) - x0; bx = k.b0x; be = k.b0e; }
-                else          { r = (k.a1 * xt + k.b1x * o[c] + k.b1e * oe) - ep; bx = k.b1x; be = k.b1e; }
-                d[c] = g * r * bx;
-                if (p.type == OUT_BOTH) d[p.C + c] = g * r * be;
-            } else {
-                const float tgt = p.rw == RW_CONSTANT ? x0 : (p.rw == RW_SNR ? ep : (-x0 * ss + ep * sa));
-                d[c] = g * (o[c] - tgt);
-            }
+        const float* ob = p.out + b * Co * p.HW;
+        float* db = dout + b * Co * p.HW;
+        const float x0 = p.x0[idx], ep = p.eps[idx], o = ob[i];
+        if (p.rw == RW_SNR_TRUNC) {
+            const int sel = aux[2 * b] >= aux[2 * b + 1] ? 0 : 1;
+            const float xt = p.xt[idx];
+            const float oe = p.type == OUT_BOTH ? ob[N + i] : 0.f;
+            float r, bx, be;
+            if (sel == 0) { r = (k.a0 * xt + k.b0x * o + k.b0e * oe) - x0; bx = k.b0x; be = k.b0e; }
+            else          { r = (k.a1 * xt + k.b1x * o + k.b1e * oe) - ep; bx = k.b1x; be = k.b1e; }
+            db[i] = g * r * bx;
+            if (p.type == OUT_BOTH) db[N + i] = g * r * be;
+        } else {
+            const float tgt = p.rw == RW_CONSTANT ? x0 : (p.rw == RW_SNR ? ep : (-x0 * ss + ep * sa));
+            db[i] = g * (o - tgt);
         }
-        const int cout = p.type == OUT_BOTH ? 2 * p.C : p.C;
-        for (int c = cout; c < ldpad; ++c) d[c] = 0.f;
     }
 }
 
 struct StepArgs {
-    const float* xt; long long ldx; const float* out; long long ldo; const float* noise; float k[8];
-    int type, cfg, last, clip; float* xn; long long ldn; int dup; float* xn_nchw; int n, C; long long HW;
+    const float* xt; const float* out; const float* noise; float k[8];
+    int type, cfg, last, clip; float* xn; float* xdup; int n, C; long long HW;
 };
 
+// one reverse step for a batch sharing the step index; x0_hat = a0*xt + b0x*o (+ b0e*o_eps), mean = c1*xt + c2*x0_hat
 __global__ void sample_step_kernel(const StepArgs p) {
-    const long long total = (long long)p.n * p.HW;
+    const long long N = (long long)p.C * p.HW, total = (long long)p.n * N;
     const float a0 = p.k[0], b0x = p.k[1], b0e = p.k[2], c1 = p.k[3], c2 = p.k[4], nscale = p.k[5], w = p.k[6];
-    const int mul = 1 + p.cfg;
+    const int mul = 1 + p.cfg, Co = p.type == OUT_BOTH ? 2 * p.C : p.C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const long long b = idx / p.HW, pix = idx % p.HW;
-        const long long row = (b * mul) * p.HW + pix;                   // conditional row; +HW = unconditional row
-        const float* xr = p.xt + row * p.ldx;
-        for (int c = 0; c < (int)p.ldn; ++c) {
-            float v = 0.f;
-            if (c < p.C) {
-                const float xt = xr[c];
-                float mean[2];
-                for (int u = 0; u < mul; ++u) {
-                    const float* o = p.out + (row + u * p.HW) * p.ldo;
-                    float x0h = a0 * xt + b0x * o[c] + (p.type == OUT_BOTH ? b0e * o[p.C + c] : 0.f);
-                    if (p.clip) x0h = fminf(fmaxf(x0h, -1.f), 1.f);
-                    mean[u] = p.last ? x0h : c1 * xt + c2 * x0h;
-                }
-                v = p.cfg ? mean[0] + w * (mean[0] - mean[1]) : mean[0];
-                v += nscale * p.noise[(b * p.C + c) * p.HW + pix];
-                if (p.xn_nchw) p.xn_nchw[(b * p.C + c) * p.HW + pix] = v;
-            }
-            const int nd = p.dup ? 2 : 1;
-            for (int u = 0; u < nd; ++u) p.xn[((b * nd + u) * p.HW + pix) * p.ldn + c] = v;
+        const long long b = idx / N, i = idx % N;
+        const float xt = p.xt[idx];
+        float mean[2];
+        for (int u = 0; u < mul; ++u) {                      // rows interleaved cond, uncond (diffusion.py:369-372)
+            const float* ob = p.out + (b * mul + u) * Co * p.HW;
+            float x0h = a0 * xt + b0x * ob[i] + (p.type == OUT_BOTH ? b0e * ob[N + i] : 0.f);
+            if (p.clip) x0h = fminf(fmaxf(x0h, -1.f), 1.f);
+            mean[u] = p.last ? x0h : c1 * xt + c2 * x0h;
         }
+        float v = p.cfg ? mean[0] + w * (mean[0] - mean[1]) : mean[0];
+        if (nscale != 0.f) v += nscale * p.noise[idx];
+        p.xn[idx] = v;
+        if (p.xdup) { p.xdup[(2 * b) * N + i] = v; p.xdup[(2 * b + 1) * N + i] = v; }
     }
 }
 
@@ -178,47 +156,46 @@ inline int grid_for(long long total) {
 
 }  // namespace
 
-extern "C" int vd_q_sample(const float* x0, const float* eps, const float* logsnr, float* xt, int64_t ld, float* xt_nchw,
-                           int32_t n, int32_t C, int32_t HW, void* stream) {
-    VD_REQUIRE(ld >= C, "vd_q_sample: ld < C");
-    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for((long long)n * HW)), dim3(256), 0, (hipStream_t)stream, x0, eps, logsnr,
-                       xt, (long long)ld, xt_nchw, n, C, (long long)HW);
+extern "C" int vd_q_sample(const float* x0, const float* eps, const float* logsnr, float* xt, int32_t n, int32_t C,
+                           int32_t HW, void* stream) {
+    const long long chw = (long long)C * HW;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(n * chw)), dim3(256), 0, (hipStream_t)stream, x0, eps, logsnr, xt,
+                       (long long)n, chw);
     VD_LAUNCH_CHECK("q_sample_kernel");
     return 0;
 }
 
-extern "C" int vd_loss_fwd(const float* x0, const float* eps, const float* xt, int64_t ldxt, const float* out, int64_t ldo,
-                           const float* logsnr, int32_t type, int32_t rw, float* loss, float* aux, int32_t n, int32_t C,
-                           int32_t HW, void* stream) {
+extern "C" int vd_loss_fwd(const float* x0, const float* eps, const float* xt, const float* out, const float* logsnr,
+                           int32_t type, int32_t rw, float* loss, float* aux, int32_t n, int32_t C, int32_t HW, void* stream) {
     VD_REQUIRE(type >= 0 && type <= 3 && rw >= 0 && rw <= 3, "vd_loss_fwd: bad model_out_type/reweight (%d,%d)", type, rw);
     VD_REQUIRE(!(type == OUT_BOTH && rw != RW_SNR_TRUNC), "vd_loss_fwd: 'both' output needs snr_trunc (reference shape rule)");
-    LossArgs p = {x0, eps, xt, ldxt, out, ldo, logsnr, type, rw, n, C, (long long)HW};
+    LossArgs p = {x0, eps, xt, out, logsnr, type, rw, n, C, (long long)HW};
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, p, loss, aux);
     VD_LAUNCH_CHECK("loss_fwd_kernel");
     return 0;
 }
 
-extern "C" int vd_loss_bwd(const float* x0, const float* eps, const float* xt, int64_t ldxt, const float* out, int64_t ldo,
-                           const float* logsnr, const float* aux, const float* gloss, int32_t type, int32_t rw, float* dout,
-                           int64_t lddo, int32_t ldpad, int32_t n, int32_t C, int32_t HW, void* stream) {
+extern "C" int vd_loss_bwd(const float* x0, const float* eps, const float* xt, const float* out, const float* logsnr,
+                           const float* aux, const float* gloss, int32_t type, int32_t rw, float* dout, int32_t n, int32_t C,
+                           int32_t HW, void* stream) {
     VD_REQUIRE(type >= 0 && type <= 3 && rw >= 0 && rw <= 3, "vd_loss_bwd: bad model_out_type/reweight");
-    LossArgs p = {x0, eps, xt, ldxt, out, ldo, logsnr, type, rw, n, C, (long long)HW};
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for((long long)n * HW)), dim3(256), 0, (hipStream_t)stream, p, aux, gloss,
-                       dout, (long long)lddo, ldpad);
+    LossArgs p = {x0, eps, xt, out, logsnr, type, rw, n, C, (long long)HW};
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for((long long)n * C * HW)), dim3(256), 0, (hipStream_t)stream, p, aux, gloss,
+                       dout);
     VD_LAUNCH_CHECK("loss_bwd_kernel");
     return 0;
 }
 
-extern "C" int vd_sample_step(const float* xt, int64_t ldx, const float* out, int64_t ldo, const float* noise, const float* k,
-                              int32_t type, int32_t cfg, int32_t last_step, int32_t clip, float* xn, int64_t ldn,
-                              int32_t dup_next, float* xn_nchw, int32_t n, int32_t C, int32_t HW, void* stream) {
+extern "C" int vd_sample_step(const float* xt, const float* out, const float* noise, const float* k, int32_t type, int32_t cfg,
+                              int32_t last_step, int32_t clip, float* xn, float* xdup, int32_t n, int32_t C, int32_t HW,
+                              void* stream) {
     VD_REQUIRE(k != nullptr, "vd_sample_step: null coefficient block (host pointer expected)");
+    VD_REQUIRE(noise != nullptr || k[5] == 0.f, "vd_sample_step: noise required when the noise scale is non-zero");
     StepArgs p = {};
-    p.xt = xt; p.ldx = ldx; p.out = out; p.ldo = ldo; p.noise = noise;
+    p.xt = xt; p.out = out; p.noise = noise;
     for (int i = 0; i < 8; ++i) p.k[i] = k[i];
-    p.type = type; p.cfg = cfg; p.last = last_step; p.clip = clip; p.xn = xn; p.ldn = ldn; p.dup = dup_next;
-    p.xn_nchw = xn_nchw; p.n = n; p.C = C; p.HW = HW;
-    hipLaunchKernelGGL(sample_step_kernel, dim3(grid_for((long long)n * HW)), dim3(256), 0, (hipStream_t)stream, p);
+    p.type = type; p.cfg = cfg; p.last = last_step; p.clip = clip; p.xn = xn; p.xdup = xdup; p.n = n; p.C = C; p.HW = HW;
+    hipLaunchKernelGGL(sample_step_kernel, dim3(grid_for((long long)n * C * HW)), dim3(256), 0, (hipStream_t)stream, p);
     VD_LAUNCH_CHECK("sample_step_kernel");
     return 0;
 }

@@ -57,11 +57,10 @@ _SIGNATURES = {
     "vd_class_embed": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_class_embed_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vd_multitag_norm": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
-    "vd_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
-    "vd_loss_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "vd_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "vd_sample_step": (C.c_int, [_vp, _i64, _vp, _i64, _vp, C.POINTER(_f32), _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp,
-                                 _i32, _i32, _i32, _vp]),
+    "vd_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "vd_sample_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(_f32), _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumsq_ws_bytes": (_sz, [_i64]),
     "vd_sumsq": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "vd_adamw_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
@@ -232,24 +231,24 @@ def multitag_norm(y, out, n, ncls):
     _check(lib().vd_multitag_norm(ptr(y), ptr(out), n, ncls, stream()), "vd_multitag_norm")
 
 
-def q_sample(x0, eps, logsnr, xt, ld, xt_nchw, n, Cc, HW):
-    _check(lib().vd_q_sample(ptr(x0), ptr(eps), ptr(logsnr), ptr(xt), ld, ptr(xt_nchw), n, Cc, HW, stream()), "vd_q_sample")
+def q_sample(x0, eps, logsnr, xt, n, Cc, HW):
+    _check(lib().vd_q_sample(ptr(x0), ptr(eps), ptr(logsnr), ptr(xt), n, Cc, HW, stream()), "vd_q_sample")
 
 
-def loss_fwd(x0, eps, xt, ldxt, out, ldo, logsnr, mot, rw, loss, aux, n, Cc, HW):
-    _check(lib().vd_loss_fwd(ptr(x0), ptr(eps), ptr(xt), ldxt, ptr(out), ldo, ptr(logsnr), mot, rw, ptr(loss), ptr(aux),
-                             n, Cc, HW, stream()), "vd_loss_fwd")
+def loss_fwd(x0, eps, xt, out, logsnr, mot, rw, loss, aux, n, Cc, HW):
+    _check(lib().vd_loss_fwd(ptr(x0), ptr(eps), ptr(xt), ptr(out), ptr(logsnr), mot, rw, ptr(loss), ptr(aux), n, Cc, HW,
+                             stream()), "vd_loss_fwd")
 
 
-def loss_bwd(x0, eps, xt, ldxt, out, ldo, logsnr, aux, gloss, mot, rw, dout, lddo, ldpad, n, Cc, HW):
-    _check(lib().vd_loss_bwd(ptr(x0), ptr(eps), ptr(xt), ldxt, ptr(out), ldo, ptr(logsnr), ptr(aux), ptr(gloss), mot, rw,
-                             ptr(dout), lddo, ldpad, n, Cc, HW, stream()), "vd_loss_bwd")
+def loss_bwd(x0, eps, xt, out, logsnr, aux, gloss, mot, rw, dout, n, Cc, HW):
+    _check(lib().vd_loss_bwd(ptr(x0), ptr(eps), ptr(xt), ptr(out), ptr(logsnr), ptr(aux), ptr(gloss), mot, rw, ptr(dout),
+                             n, Cc, HW, stream()), "vd_loss_bwd")
 
 
-def sample_step(xt, ldx, out, ldo, noise, k8, mot, cfg, last, clip, xn, ldn, dup, xn_nchw, n, Cc, HW):
+def sample_step(xt, out, noise, k8, mot, cfg, last, clip, xn, xdup, n, Cc, HW):
     arr = (_f32 * 8)(*[float(v) for v in k8])
-    _check(lib().vd_sample_step(ptr(xt), ldx, ptr(out), ldo, ptr(noise), arr, mot, int(cfg), int(last), int(clip), ptr(xn),
-                                ldn, int(dup), ptr(xn_nchw), n, Cc, HW, stream()), "vd_sample_step")
+    _check(lib().vd_sample_step(ptr(xt), ptr(out), ptr(noise), arr, mot, int(cfg), int(last), int(clip), ptr(xn), ptr(xdup),
+                                n, Cc, HW, stream()), "vd_sample_step")
 
 
 def sumsq(g, out1):

@@ -1,0 +1,519 @@
+"""Explicit forward/backward engine of the UNet on the HIP kernels (no autograd graph inside, no tracing compiler).
+
+Replaces what ATen/cuDNN/cuBLAS + autograd do for reference ``UNet.forward`` (v_diffusion/models/unet.py:286-322),
+``ResidualBlock.forward`` (:137-148) and ``AttentionBlock.forward`` (:55-81).
+
+Data layout in HBM
+  * activations: NHWC fp32 ``[B, H, W, C]`` torch buffers; a tensor handed between ops is a *view* whose
+    ``stride(2)`` (= per-pixel stride ``ld``) may exceed C.  The concat of reference unet.py:315 is never
+    materialised: each up-block owns one ``[B,H,W,Ch+Cs]`` buffer, the producer of ``h`` writes channels
+    ``[0,Ch)`` and the producer of the skip tensor (a down-block, run much earlier) writes ``[Ch,Ch+Cs)``
+    directly from their conv epilogues; gradients flow back the same way (the down-block's input gradient is
+    accumulated into the skip slice of the up-block's input gradient).
+  * weights stay in the reference's OIHW / (out,in) storage; 3x3 kernels are re-packed to [Cout][tap][Cin]
+    (forward) and [Cin][tap'][Cout] (input gradient) per call -- 0.3 ms per UNet pass, always coherent with
+    whatever mutated the parameters (optimizer, load_state_dict, EMA swap through ``.data``).
+  * the tape (what backward needs) is a python list of per-block dicts of buffers; with 288 GB of HBM nothing is
+    recomputed except the dropout mask (counter-based Philox, regenerated from (seed, element index)).
+"""
+import math
+
+import torch
+
+from . import _hip as H
+
+GROUPS = 32
+EPS = 1e-6
+
+
+def _ld(t):
+    return t.stride(2)
+
+
+def _chk(t):
+    B, Hh, Ww, C = t.shape
+    ld = t.stride(2)
+    assert t.stride(3) == 1 and t.stride(1) == Ww * ld and t.stride(0) == Hh * Ww * ld, "not an NHWC view"
+    return B, Hh, Ww, C, ld
+
+
+def _splitk(M, N, K):
+    """split-K factor for the small-output weight-gradient GEMMs (K = batch*pixels)."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    s = max(1, min(64, 512 // max(tiles, 1), K // 256))
+    return s
+
+
+class _Blk:
+    __slots__ = ("prefix", "kind", "cin", "cout", "rs", "attn", "consumes", "res", "att", "level", "dest", "src_hs", "push_hs",
+                 "ch_h")
+
+
+class UNetEngine:
+    """Static execution plan + forward/backward drivers for one ``UNet`` module."""
+
+    def __init__(self, model):
+        self.m = model
+        hid, mult, nrb = model.hid_channels, list(model.ch_multipliers), model.num_res_blocks
+        levels = len(mult)
+        chs = [hid * k for k in mult]
+        plan = []
+
+        def add(prefix, kind, cin, cout, rs, attn, consumes, level, container):
+            b = _Blk()
+            b.prefix, b.kind, b.cin, b.cout, b.rs, b.attn, b.consumes, b.level = prefix, kind, cin, cout, rs, attn, consumes, level
+            if kind == "midattn":
+                b.res, b.att = None, container
+            elif attn:
+                b.res, b.att = container[0], container[1]
+            else:
+                b.res, b.att = container, None
+            plan.append(b)
+
+        for i in range(levels):                                               # reference unet.py:250-263
+            mods = model.downsamples[f"level_{i}"]
+            prev = chs[i - 1] if i else hid
+            for j in range(nrb):
+                add(f"downsamples.level_{i}.{j}", "down", prev if j == 0 else chs[i], chs[i], H.RS_NONE, model.apply_attn[i],
+                    False, i, mods[j])
+            if i != levels - 1:
+                add(f"downsamples.level_{i}.{nrb}", "down", chs[i], chs[i], H.RS_DOWN, model.apply_attn[i], False, i, mods[nrb])
+        add("middle.0", "mid", chs[-1], chs[-1], H.RS_NONE, False, False, levels - 1, model.middle[0])
+        add("middle.1", "midattn", chs[-1], chs[-1], H.RS_NONE, True, False, levels - 1, model.middle[1])
+        add("middle.2", "mid", chs[-1], chs[-1], H.RS_NONE, False, False, levels - 1, model.middle[2])
+        for i in range(levels - 1, -1, -1):                                   # reference unet.py:265-284
+            mods = model.upsamples[f"level_{i}"]
+            nxt = hid if i == 0 else chs[i - 1]
+            prv = chs[-1] if i == levels - 1 else chs[i + 1]
+            cins = [prv + chs[i]] + [2 * chs[i]] * (nrb - 1) + [nxt + chs[i]]
+            for j, cin in enumerate(cins):
+                add(f"upsamples.level_{i}.{j}", "up", cin, chs[i], H.RS_NONE, model.apply_attn[i], True, i, mods[j])
+            if i != 0:
+                add(f"upsamples.level_{i}.{nrb + 1}", "up", chs[i], chs[i], H.RS_UP, model.apply_attn[i], False, i, mods[nrb + 1])
+        self.plan = plan
+        # ---- static skip-stack analysis: which concat buffer does every pushed tensor land in?
+        stack = [("in_conv", hid)]                       # (producer, channels); hs ids are positions in `pushes`
+        pushes = [["in_conv", hid, None, None]]          # [producer, Cs, consumer block index, Ch]
+        sid = [0]
+        for bi, b in enumerate(plan):
+            b.push_hs = None
+            b.src_hs = None
+            b.ch_h = None
+            if b.kind == "down":
+                pushes.append([bi, b.cout, None, None])
+                sid.append(len(pushes) - 1)
+                b.push_hs = len(pushes) - 1
+            elif b.consumes:
+                k = sid.pop()
+                b.src_hs = k
+                b.ch_h = b.cin - pushes[k][1]
+                pushes[k][2], pushes[k][3] = bi, b.ch_h
+        assert not sid, "skip stack not emptied"
+        self.pushes = pushes
+        for bi, b in enumerate(plan):                    # where does each block write its output?
+            if b.kind == "down":
+                k = b.push_hs
+                b.dest = ("cat", pushes[k][2], pushes[k][3], pushes[k][1])
+            else:
+                nxt = plan[bi + 1] if bi + 1 < len(plan) else None
+                b.dest = ("cat", bi + 1, 0, b.cout) if (nxt is not None and nxt.consumes) else ("plain",)
+        self.levels = levels
+
+    # ------------------------------------------------------------------------------------------ small helpers
+    @staticmethod
+    def _new(ref, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+    def _res_of(self, level, H0, W0):
+        return H0 >> level, W0 >> level
+
+    def _pack_f(self, w, cin_p=None):
+        co, ci = w.shape[0], w.shape[1]
+        cin_p = cin_p or ci
+        wf = self._new(w, co, 9, cin_p)
+        H.pack_conv3x3(w, co, ci, wf=wf, Cin_p=cin_p)
+        return wf
+
+    def _pack_d(self, w, cout_p=None):
+        co, ci = w.shape[0], w.shape[1]
+        cout_p = cout_p or co
+        wd = self._new(w, ci, 9, cout_p)
+        H.pack_conv3x3(w, co, ci, wd=wd, Cout_p=cout_p)
+        return wd
+
+    @staticmethod
+    def _linear(x, w, b, out, accumulate=False):
+        """out[M,N] (+)= x[M,K] @ w[N,K]^T + b"""
+        M, K = x.shape
+        N = w.shape[0]
+        H.gemm(x, w, out, M, N, K, a_kind=H.ROW, b_kind=H.ROW, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b,
+               accumulate=accumulate)
+
+    @staticmethod
+    def _linear_bwd(x, w, dy, dw, db, dx, dx_accumulate=False):
+        """dw[N,K] = dy^T x ; db[N] = colsum(dy) ; dx[M,K] (+)= dy @ w"""
+        M, K = x.shape
+        N = w.shape[0]
+        H.gemm(dy, x, dw, N, K, M, a_kind=H.COL, b_kind=H.COL, lda=dy.stride(0), ldb=x.stride(0), ldc=K, splitk=_splitk(N, K, M))
+        if db is not None:
+            H.colsum(dy, dy.stride(0), M, N, db)
+        if dx is not None:
+            H.gemm(dy, w, dx, M, K, N, a_kind=H.ROW, b_kind=H.COL, lda=dy.stride(0), ldb=w.stride(0), ldc=dx.stride(0),
+                   accumulate=dx_accumulate)
+
+    # ------------------------------------------------------------------------------------------ embeddings
+    def _embed_fwd(self, t, y, tape):
+        m = self.m
+        B = t.shape[0]
+        dev_ref = m.in_conv.weight
+        if t.dtype != torch.float64:
+            t = t.to(torch.float64)
+        te0 = self._new(dev_ref, B, m.hid_channels)
+        H.timestep_embedding(t.contiguous(), te0, B, m.hid_channels)
+        l0, l2 = m.time_embed[0], m.time_embed[2]
+        h0 = self._new(dev_ref, B, m.embedding_dim)
+        self._linear(te0, l0.weight, l0.bias, h0)
+        a0 = torch.empty_like(h0)
+        H.silu(h0, a0)
+        te = torch.empty_like(h0)
+        self._linear(a0, l2.weight, l2.bias, te)
+        yn = None
+        if m.num_classes and y is not None:
+            y = y.to(torch.float32).contiguous().clone()      # callers mutate y after the forward (diffusion.py:527-529)
+            if m.multitags:
+                assert y.ndim == 2 and y.shape[1] == m.num_classes
+                yn = torch.empty_like(y)
+                H.multitag_norm(y, yn, B, m.num_classes)
+                self._linear(yn, m.class_embed.weight, m.class_embed.bias, te, accumulate=True)
+            else:
+                lin = m.class_embed[1]
+                H.class_embed(y.reshape(-1), lin.weight, lin.bias, te, B, m.embedding_dim, m.num_classes)
+                yn = y.reshape(-1)
+        ta = torch.empty_like(te)
+        H.silu(te, ta)
+        if tape is not None:
+            tape["embed"] = dict(te0=te0, h0=h0, a0=a0, te=te, yn=yn)
+        return ta
+
+    def _embed_bwd(self, ctx, dta, G):
+        m = self.m
+        B = dta.shape[0]
+        te0, h0, a0, te, yn = ctx["te0"], ctx["h0"], ctx["a0"], ctx["te"], ctx["yn"]
+        dte = torch.empty_like(dta)
+        H.silu_bwd(te, dta, dte)
+        if yn is not None:
+            if m.multitags:
+                self._linear_bwd(yn, m.class_embed.weight, dte, G["class_embed.weight"], G["class_embed.bias"], None)
+            else:
+                H.class_embed_bwd(yn, dte, G["class_embed.1.weight"], G["class_embed.1.bias"], B, m.embedding_dim, m.num_classes)
+        l0, l2 = m.time_embed[0], m.time_embed[2]
+        da0 = torch.empty_like(dte)
+        self._linear_bwd(a0, l2.weight, dte, G["time_embed.2.weight"], G["time_embed.2.bias"], da0)
+        dh0 = torch.empty_like(da0)
+        H.silu_bwd(h0, da0, dh0)
+        self._linear_bwd(te0, l0.weight, dh0, G["time_embed.0.weight"], G["time_embed.0.bias"], None)
+
+    # ------------------------------------------------------------------------------------------ residual block
+    def _res_fwd(self, blk, mod, prefix, x, ta, dest, p_drop, seed, tape):
+        B, Hh, Ww, Cin, ldx = _chk(x)
+        Cout, rs = blk.cout, blk.rs
+        Ho, Wo = (Hh // 2, Ww // 2) if rs == H.RS_DOWN else ((Hh * 2, Ww * 2) if rs == H.RS_UP else (Hh, Ww))
+        stats1, coef1 = self._new(x, B, GROUPS, 2), self._new(x, B, 4, Cin)
+        H.gn_stats(x, ldx, B, Hh * Ww, Cin, stats1, GROUPS, EPS)
+        a1 = self._new(x, B, Ho, Wo, Cin)
+        H.gn_apply(x, ldx, stats1, mod.norm1.weight, mod.norm1.bias, None, 1, 0.0, 0, rs, a1, Cin, B, Hh, Ww, Cin, coef1, GROUPS)
+        h1 = self._new(x, B, Ho, Wo, Cout)
+        H.conv3x3(a1, Cin, self._pack_f(mod.conv1.weight), mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout)
+        film = self._new(x, B, 2 * Cout)
+        self._linear(ta, mod.fc.weight, mod.fc.bias, film)
+        stats2, coef2 = self._new(x, B, GROUPS, 2), self._new(x, B, 4, Cout)
+        H.gn_stats(h1, Cout, B, Ho * Wo, Cout, stats2, GROUPS, EPS)
+        a2 = self._new(x, B, Ho, Wo, Cout)
+        H.gn_apply(h1, Cout, stats2, mod.norm2.weight, mod.norm2.bias, film, 1, p_drop, seed, H.RS_NONE, a2, Cout, B, Ho, Wo, Cout,
+                   coef2, GROUPS)
+        if rs != H.RS_NONE:
+            xs = self._new(x, B, Ho, Wo, Cin)
+            H.gn_apply(x, ldx, None, None, None, None, 0, 0.0, 0, rs, xs, Cin, B, Hh, Ww, Cin, None, GROUPS)
+        else:
+            xs = x
+        has_skip = Cin != Cout
+        if has_skip:
+            sk = self._new(x, B, Ho, Wo, Cout)
+            w = mod.skip.weight
+            H.gemm(xs, w, sk, B * Ho * Wo, Cout, Cin, a_kind=H.ROW, b_kind=H.ROW, lda=_ld(xs), ldb=Cin, ldc=Cout, bias=mod.skip.bias)
+        else:
+            sk = xs
+        H.conv3x3(a2, Cout, self._pack_f(mod.conv2.weight), mod.conv2.bias, dest, _ld(dest), B, Ho, Wo, Cout, Cout, res=sk,
+                  ldres=_ld(sk))
+        if tape is not None:
+            tape[prefix] = dict(x=x, coef1=coef1, a1=a1, h1=h1, coef2=coef2, a2=a2, film=film, xs=xs if has_skip else None,
+                                seed=seed, p=p_drop, ta=ta)
+
+    def _res_bwd(self, blk, mod, prefix, ctx, dy, dx, dx_accumulate, dta, G):
+        x, a1, h1, a2, film = ctx["x"], ctx["a1"], ctx["h1"], ctx["a2"], ctx["film"]
+        B, Hh, Ww, Cin, ldx = _chk(x)
+        _, Ho, Wo, Cout, lddy = _chk(dy)
+        rs = blk.rs
+        # conv2
+        H.conv3x3_wgrad(a2, Cout, dy, lddy, B, Ho, Wo, Cout, Cout, G[prefix + ".conv2.weight"], Cout, Cout)
+        H.colsum(dy, lddy, B * Ho * Wo, Cout, G[prefix + ".conv2.bias"])
+        da2 = self._new(x, B, Ho, Wo, Cout)
+        H.conv3x3(dy, lddy, self._pack_d(mod.conv2.weight), None, da2, Cout, B, Ho, Wo, Cout, Cout)
+        # norm2 + FiLM + SiLU + dropout
+        dh1 = self._new(x, B, Ho, Wo, Cout)
+        dfilm = self._new(x, B, 2 * Cout)
+        H.gn_apply_bwd(da2, Cout, h1, Cout, ctx["coef2"], mod.norm2.weight, mod.norm2.bias, film, 1, ctx["p"], ctx["seed"],
+                       H.RS_NONE, None, 0, dh1, Cout, False, dfilm, G[prefix + ".norm2.weight"], G[prefix + ".norm2.bias"], False,
+                       B, Ho, Wo, Cout, GROUPS)
+        del da2
+        # conv1
+        H.conv3x3_wgrad(a1, Cin, dh1, Cout, B, Ho, Wo, Cin, Cout, G[prefix + ".conv1.weight"], Cin, Cout)
+        H.colsum(dh1, Cout, B * Ho * Wo, Cout, G[prefix + ".conv1.bias"])
+        da1 = self._new(x, B, Ho, Wo, Cin)
+        H.conv3x3(dh1, Cout, self._pack_d(mod.conv1.weight), None, da1, Cin, B, Ho, Wo, Cout, Cin)
+        del dh1
+        # skip path
+        if Cin != Cout:
+            xs = ctx["xs"]
+            P = B * Ho * Wo
+            w = mod.skip.weight
+            H.gemm(dy, xs, G[prefix + ".skip.weight"], Cout, Cin, P, a_kind=H.COL, b_kind=H.COL, lda=lddy, ldb=_ld(xs), ldc=Cin,
+                   splitk=_splitk(Cout, Cin, P))
+            H.colsum(dy, lddy, P, Cout, G[prefix + ".skip.bias"])
+            dsk = self._new(x, B, Ho, Wo, Cin)
+            H.gemm(dy, w, dsk, P, Cin, Cout, a_kind=H.ROW, b_kind=H.COL, lda=lddy, ldb=Cin, ldc=Cin)
+        else:
+            dsk = dy
+        if rs != H.RS_NONE:
+            addt = self._new(x, B, Hh, Ww, Cin)
+            H.gn_apply_bwd(dsk, _ld(dsk), None, 0, None, None, None, None, 0, 0.0, 0, rs, None, 0, addt, Cin, False, None, None,
+                           None, False, B, Hh, Ww, Cin, GROUPS)
+        else:
+            addt = dsk
+        # norm1 + SiLU (+ resample) and the sum with the skip-path gradient
+        H.gn_apply_bwd(da1, Cin, x, ldx, ctx["coef1"], mod.norm1.weight, mod.norm1.bias, None, 1, 0.0, 0, rs, addt, _ld(addt),
+                       dx, _ld(dx), dx_accumulate, None, G[prefix + ".norm1.weight"], G[prefix + ".norm1.bias"], False,
+                       B, Hh, Ww, Cin, GROUPS)
+        # FiLM projection: film = fc(ta)
+        ta = ctx["ta"]
+        self._linear_bwd(ta, mod.fc.weight, dfilm, G[prefix + ".fc.weight"], G[prefix + ".fc.bias"], dta, dx_accumulate=True)
+
+    # ------------------------------------------------------------------------------------------ attention block
+    def _attn_fwd(self, mod, prefix, x, dest, tape):
+        B, Hh, Ww, C, ldx = _chk(x)
+        L, nh, hd = Hh * Ww, mod.num_heads, mod.head_dim
+        hid = nh * hd
+        stats, coef = self._new(x, B, GROUPS, 2), self._new(x, B, 4, C)
+        H.gn_stats(x, ldx, B, L, C, stats, GROUPS, EPS)
+        xn = self._new(x, B, Hh, Ww, C)
+        H.gn_apply(x, ldx, stats, mod.norm.weight, mod.norm.bias, None, 0, 0.0, 0, H.RS_NONE, xn, C, B, Hh, Ww, C, coef, GROUPS)
+        qkv = self._new(x, B, L, 3 * hid)
+        H.gemm(xn, mod.proj_in.weight, qkv, B * L, 3 * hid, C, a_kind=H.ROW, b_kind=H.ROW, lda=C, ldb=C, ldc=3 * hid,
+               bias=mod.proj_in.bias)
+        ld = 3 * hid
+        S = self._new(x, B, nh, L, L)
+        alpha = 1.0 / math.sqrt(hd)
+        q, k, v = qkv[0, 0, 0:], qkv[0, 0, hid:], qkv[0, 0, 2 * hid:]
+        H.gemm(q, k, S, L, L, hd, a_kind=H.ROW, b_kind=H.ROW, lda=ld, ldb=ld, ldc=L, batch=B * nh, nh=nh, sA=(L * ld, hd),
+               sB=(L * ld, hd), sC=(nh * L * L, L * L), alpha=alpha)
+        H.softmax_rows(S, B * nh * L, L)
+        O = self._new(x, B, L, hid)
+        H.gemm(S, v, O, L, hd, L, a_kind=H.ROW, b_kind=H.COL, lda=L, ldb=ld, ldc=hid, batch=B * nh, nh=nh, sA=(nh * L * L, L * L),
+               sB=(L * ld, hd), sC=(L * hid, hd))
+        H.gemm(O, mod.proj_out.weight, dest, B * L, C, hid, a_kind=H.ROW, b_kind=H.ROW, lda=hid, ldb=hid, ldc=_ld(dest),
+               bias=mod.proj_out.bias, R=x, ldr=ldx)
+        if tape is not None:
+            tape[prefix] = dict(x=x, coef=coef, xn=xn, qkv=qkv, P=S, O=O)
+
+    def _attn_bwd(self, mod, prefix, ctx, dy, dx, dx_accumulate, G):
+        x, xn, qkv, P, O = ctx["x"], ctx["xn"], ctx["qkv"], ctx["P"], ctx["O"]
+        B, Hh, Ww, C, ldx = _chk(x)
+        lddy = _ld(dy)
+        L, nh, hd = Hh * Ww, mod.num_heads, mod.head_dim
+        hid, ld = nh * hd, 3 * nh * hd
+        M = B * L
+        # proj_out
+        H.gemm(dy, O, G[prefix + ".proj_out.weight"], C, hid, M, a_kind=H.COL, b_kind=H.COL, lda=lddy, ldb=hid, ldc=hid,
+               splitk=_splitk(C, hid, M))
+        H.colsum(dy, lddy, M, C, G[prefix + ".proj_out.bias"])
+        dO = self._new(x, B, L, hid)
+        H.gemm(dy, mod.proj_out.weight, dO, M, hid, C, a_kind=H.ROW, b_kind=H.COL, lda=lddy, ldb=hid, ldc=hid)
+        dqkv = self._new(x, B, L, ld)
+        q, k, v = qkv[0, 0, 0:], qkv[0, 0, hid:], qkv[0, 0, 2 * hid:]
+        dq, dk, dv = dqkv[0, 0, 0:], dqkv[0, 0, hid:], dqkv[0, 0, 2 * hid:]
+        sP, sQ, sO = (nh * L * L, L * L), (L * ld, hd), (L * hid, hd)
+        # dV[j][d] = sum_l P[l][j] dO[l][d]
+        H.gemm(P, dO, dv, L, hd, L, a_kind=H.COL, b_kind=H.COL, lda=L, ldb=hid, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sO, sC=sQ)
+        # dP[l][j] = sum_d dO[l][d] V[j][d]
+        dP = self._new(x, B, nh, L, L)
+        H.gemm(dO, v, dP, L, L, hd, a_kind=H.ROW, b_kind=H.ROW, lda=hid, ldb=ld, ldc=L, batch=B * nh, nh=nh, sA=sO, sB=sQ, sC=sP)
+        alpha = 1.0 / math.sqrt(hd)
+        H.softmax_rows_bwd(P, dP, B * nh * L, L, alpha)                 # dP <- dS (already scaled by 1/sqrt(hd))
+        # dQ[l][d] = sum_j dS[l][j] K[j][d] ; dK[j][d] = sum_l dS[l][j] Q[l][d]
+        H.gemm(dP, k, dq, L, hd, L, a_kind=H.ROW, b_kind=H.COL, lda=L, ldb=ld, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sQ, sC=sQ)
+        H.gemm(dP, q, dk, L, hd, L, a_kind=H.COL, b_kind=H.COL, lda=L, ldb=ld, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sQ, sC=sQ)
+        del dP, dO
+        # proj_in
+        H.gemm(dqkv, xn, G[prefix + ".proj_in.weight"], ld, C, M, a_kind=H.COL, b_kind=H.COL, lda=ld, ldb=C, ldc=C,
+               splitk=_splitk(ld, C, M))
+        H.colsum(dqkv, ld, M, ld, G[prefix + ".proj_in.bias"])
+        dxn = self._new(x, B, Hh, Ww, C)
+        H.gemm(dqkv, mod.proj_in.weight, dxn, M, C, ld, a_kind=H.ROW, b_kind=H.COL, lda=ld, ldb=C, ldc=C)
+        # norm (no activation) + the residual branch
+        H.gn_apply_bwd(dxn, C, x, ldx, ctx["coef"], mod.norm.weight, mod.norm.bias, None, 0, 0.0, 0, H.RS_NONE, dy, lddy, dx,
+                       _ld(dx), dx_accumulate, None, G[prefix + ".norm.weight"], G[prefix + ".norm.bias"], False, B, Hh, Ww, C,
+                       GROUPS)
+
+    # ------------------------------------------------------------------------------------------ whole network
+    def forward(self, x_nchw, t, y, training, save):
+        """x (B,Cin,H,W) NCHW -> output NHWC ``[B,H,W,Cp]`` (Cp = out_channels rounded up to 4) and the tape."""
+        m = self.m
+        B, Ci, H0, W0 = x_nchw.shape
+        assert Ci == m.in_channels and H0 % (1 << (self.levels - 1)) == 0 and W0 % (1 << (self.levels - 1)) == 0
+        tape = {} if save else None
+        x_nchw = x_nchw.to(torch.float32).contiguous()
+        ta = self._embed_fwd(t, y, tape)
+        p_drop = float(m.drop_rate) if training else 0.0
+        base_seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p_drop > 0 else 0
+        cip = (Ci + 3) // 4 * 4
+        x4 = self._new(x_nchw, B, H0, W0, cip)
+        H.nchw_to_nhwc(x_nchw, x4, B, Ci, H0, W0, cip)
+        # concat buffers, one per consuming up-block
+        cats = {}
+        for bi, b in enumerate(self.plan):
+            if b.consumes:
+                hh, ww = self._res_of(b.level, H0, W0)
+                cats[bi] = self._new(x_nchw, B, hh, ww, b.cin)
+
+        def dest_of(spec, hh, ww):
+            if spec[0] == "cat":
+                _, u, c0, c = spec
+                return cats[u][..., c0:c0 + c]
+            return self._new(x_nchw, B, hh, ww, spec[1])
+
+        p0 = self.pushes[0]
+        d = dest_of(("cat", p0[2], p0[3], p0[1]), H0, W0)
+        H.conv3x3(x4, cip, self._pack_f(m.in_conv.weight, cip), m.in_conv.bias, d, _ld(d), B, H0, W0, cip, m.hid_channels)
+        hs_top, h = d, None
+        for bi, b in enumerate(self.plan):
+            if b.kind == "down":
+                inp = hs_top
+            elif b.kind in ("mid", "midattn"):
+                inp = hs_top if h is None else h
+            else:
+                inp = cats[bi] if b.consumes else h
+            _, ih, iw, _, _ = _chk(inp)
+            oh, ow = (ih // 2, iw // 2) if b.rs == H.RS_DOWN else ((ih * 2, iw * 2) if b.rs == H.RS_UP else (ih, iw))
+            spec = b.dest if b.dest[0] == "cat" else ("plain", b.cout)
+            out = dest_of(spec, oh, ow)
+            if b.kind == "midattn":
+                self._attn_fwd(b.att, b.prefix, inp, out, tape)
+            elif b.att is not None:
+                mid = self._new(x_nchw, B, oh, ow, b.cout)
+                self._res_fwd(b, b.res, b.prefix + ".0", inp, ta, mid, p_drop, base_seed + 2 * bi + 1, tape)
+                self._attn_fwd(b.att, b.prefix + ".1", mid, out, tape)
+            else:
+                self._res_fwd(b, b.res, b.prefix, inp, ta, out, p_drop, base_seed + 2 * bi + 1, tape)
+            if b.kind == "down":
+                hs_top = out
+            else:
+                h = out
+        # out_conv: GN -> SiLU -> 3x3
+        C0 = m.hid_channels * m.ch_multipliers[0]
+        gn, conv = m.out_conv[0], m.out_conv[2]
+        stats, coef = self._new(h, B, GROUPS, 2), self._new(h, B, 4, C0)
+        H.gn_stats(h, _ld(h), B, H0 * W0, C0, stats, GROUPS, EPS)
+        a = self._new(h, B, H0, W0, C0)
+        H.gn_apply(h, _ld(h), stats, gn.weight, gn.bias, None, 1, 0.0, 0, H.RS_NONE, a, C0, B, H0, W0, C0, coef, GROUPS)
+        co = m.out_channels
+        cop = (co + 3) // 4 * 4
+        out = torch.zeros((B, H0, W0, cop), dtype=torch.float32, device=h.device)
+        H.conv3x3(a, C0, self._pack_f(conv.weight), conv.bias, out, cop, B, H0, W0, C0, co)
+        if tape is not None:
+            tape["ta"] = ta
+            tape["in"] = dict(x4=x4)
+            tape["out"] = dict(h=h, coef=coef, a=a)
+        return out, tape
+
+    def new_grads(self):
+        return {k: torch.empty_like(p) for k, p in self.m.named_parameters()}
+
+    def backward(self, tape, dout, G, need_dx=False):
+        """dout: NHWC ``[B,H,W,Cp]`` gradient of the padded output (padding channels zero).  Fills ``G`` (name -> tensor,
+        every entry overwritten) and returns d/dx (NCHW) when asked."""
+        m = self.m
+        B, H0, W0, cop, _ = _chk(dout)
+        ta = tape["ta"]
+        dta = torch.zeros_like(ta)
+        # ---- out_conv
+        C0 = m.hid_channels * m.ch_multipliers[0]
+        gn, conv = m.out_conv[0], m.out_conv[2]
+        o = tape["out"]
+        co = m.out_channels
+        H.conv3x3_wgrad(o["a"], C0, dout, cop, B, H0, W0, C0, cop, G["out_conv.2.weight"], C0, co)
+        bt = self._new(dout, cop)
+        H.colsum(dout, cop, B * H0 * W0, cop, bt)
+        G["out_conv.2.bias"].copy_(bt[:co])
+        da = self._new(dout, B, H0, W0, C0)
+        H.conv3x3(dout, cop, self._pack_d(conv.weight, cop), None, da, C0, B, H0, W0, cop, C0)
+        dh = self._new(dout, B, H0, W0, C0)
+        H.gn_apply_bwd(da, C0, o["h"], _ld(o["h"]), o["coef"], gn.weight, gn.bias, None, 1, 0.0, 0, H.RS_NONE, None, 0, dh, C0,
+                       False, None, G["out_conv.0.weight"], G["out_conv.0.bias"], False, B, H0, W0, C0, GROUPS)
+        del da
+        # ---- blocks in reverse
+        dskip = {}                     # hs id -> gradient view (written by the consuming up-block)
+        dh_cur = dh                    # gradient of the running `h`
+        for bi in range(len(self.plan) - 1, -1, -1):
+            b = self.plan[bi]
+            first_ctx = tape[b.prefix + ".0"] if (b.att is not None and b.kind != "midattn") else tape[b.prefix]
+            xin = first_ctx["x"]
+            Bx, ih, iw, cin, _ = _chk(xin)
+            if b.kind == "down":
+                dy = dskip.pop(b.push_hs)                       # total gradient of the tensor this block pushed
+            else:
+                dy = dh_cur
+            # where does the input gradient go?  Blocks that read the top of the skip stack (every down block and
+            # middle.0) accumulate into the slot the consuming up-block already filled; everything else gets a fresh buffer.
+            if b.kind == "down" or b.prefix == "middle.0":
+                dxbuf, acc = dskip[self._hs_feeding(bi)], True
+            else:
+                dxbuf, acc = self._new(dout, Bx, ih, iw, cin), False
+            if b.kind == "midattn":
+                self._attn_bwd(b.att, b.prefix, tape[b.prefix], dy, dxbuf, acc, G)
+            elif b.att is not None:
+                dmid = self._new(dout, *tape[b.prefix + ".1"]["x"].shape)
+                self._attn_bwd(b.att, b.prefix + ".1", tape[b.prefix + ".1"], dy, dmid, False, G)
+                self._res_bwd(b, b.res, b.prefix + ".0", tape[b.prefix + ".0"], dmid, dxbuf, acc, dta, G)
+                del dmid
+            else:
+                self._res_bwd(b, b.res, b.prefix, tape[b.prefix], dy, dxbuf, acc, dta, G)
+            if b.kind == "up" and b.consumes:
+                dh_cur = dxbuf[..., :b.ch_h]
+                dskip[b.src_hs] = dxbuf[..., b.ch_h:]
+            elif not acc:
+                dh_cur = dxbuf
+        # ---- in_conv
+        dy0 = dskip.pop(0)
+        assert not dskip
+        x4 = tape["in"]["x4"]
+        cip = x4.shape[3]
+        H.conv3x3_wgrad(x4, cip, dy0, _ld(dy0), B, H0, W0, cip, m.hid_channels, G["in_conv.weight"], m.in_channels, m.hid_channels)
+        H.colsum(dy0, _ld(dy0), B * H0 * W0, m.hid_channels, G["in_conv.bias"])
+        dx = None
+        if need_dx:
+            d4 = self._new(dout, B, H0, W0, cip)
+            if cip != m.in_channels:
+                d4.zero_()
+            H.conv3x3(dy0, _ld(dy0), self._pack_d(m.in_conv.weight, m.hid_channels), None, d4, cip, B, H0, W0, m.hid_channels,
+                      m.in_channels)
+            dx = self._new(dout, B, m.in_channels, H0, W0)
+            H.nhwc_to_nchw(d4, cip, dx, B, m.in_channels, H0, W0)
+        self._embed_bwd(tape["embed"], dta, G)
+        return dx
+
+    def _hs_feeding(self, bi):
+        """id of the skip-stack entry that block ``bi`` reads as its input (the stack top at that time)."""
+        b = self.plan[bi]
+        if b.kind == "down":
+            return b.push_hs - 1
+        return len(self.pushes) - 1          # middle.0 reads the last pushed tensor
