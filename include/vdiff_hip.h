@@ -60,6 +60,9 @@ typedef struct vd_gemm_desc {
 /* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two
  * einsum contractions of attention (unet.py:57,61-63) and all of their autograd backward GEMMs */
 int vd_gemm(const vd_gemm_desc* d, void* stream);
+/* block tile (128 or 64) the calling thread's last vd_gemm / vd_conv3x3* launch used (profiling aid: names the kernel
+ * instantiation gemm_kernel<tile,tile,a_kind,b_kind,splitk> a launch went to) */
+int vd_gemm_last_tile(void);
 
 /* 3x3 / stride 1 / pad 1 convolution, NHWC (replaces F.conv2d at modules.py:141-144 <- unet.py:121,125,217,232).
  *   y[b,y,x,co] = bias[co] + res[b,y,x,co] + sum_{tap,ci} xin[b,y+dy,x+dx,ci] * wpack[co][tap][ci]

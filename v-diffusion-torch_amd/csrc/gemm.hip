@@ -88,15 +88,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         }
     }
     const int cchA = (AK == VD_IM2COL) ? (p.Cin + KT - 1) / KT : 1;
+    // K-tile cursor of the im2col A operand: (tap, channel chunk), advanced once per load_tiles call (tiles are
+    // visited in order), so the main loop has no integer division
+    int tapA = (AK == VD_IM2COL) ? kt_begin / cchA : 0;
+    int ccA = (AK == VD_IM2COL) ? kt_begin % cchA : 0;
+    // pixel cursor of the im2col B operand (wgrad): image coordinates of this thread's k rows
+    int by[BIT], bx[BIT];
+    const int kinc_x = (BK == VD_IM2COL) ? KT % p.W : 0, kinc_y = (BK == VD_IM2COL) ? KT / p.W : 0;
+    if (BK == VD_IM2COL) {
+#pragma unroll
+        for (int it = 0; it < BIT; ++it) {
+            const int k = kt_begin * KT + tid / B_CPR + it * B_RPP;
+            const int rem = k % (p.H * p.W);
+            by[it] = rem / p.W;
+            bx[it] = rem % p.W;
+        }
+    }
 
     f32x4 ra[AIT], rb[BIT];
 
     auto load_tiles = [&](int kt) {
         // ---------------- A
+        const int tap = tapA, c0 = ccA * KT;
         if (AK == VD_ROW || AK == VD_IM2COL) {
             int kbase, kwidth, dy = 0, dx = 0;
             if (AK == VD_IM2COL) {
-                const int tap = kt / cchA, c0 = (kt % cchA) * KT;
                 dy = tap / 3 - 1; dx = tap % 3 - 1;
                 kbase = c0; kwidth = p.Cin - c0;
             } else { kbase = kt * KT; kwidth = p.K - kbase; }
@@ -127,10 +143,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         // ---------------- B
         if (BK == VD_ROW) {
             int kbase, kwidth;
-            if (AK == VD_IM2COL) {
-                const int tap = kt / cchA, c0 = (kt % cchA) * KT;
-                kbase = tap * p.Cin + c0; kwidth = p.Cin - c0;
-            } else { kbase = kt * KT; kwidth = p.K - kbase; }
+            if (AK == VD_IM2COL) { kbase = tap * p.Cin + c0; kwidth = p.Cin - c0; }
+            else { kbase = kt * KT; kwidth = p.K - kbase; }
             const int ck = r_chunk * 4;
 #pragma unroll
             for (int it = 0; it < BIT; ++it) {
@@ -154,14 +168,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             for (int it = 0; it < BIT; ++it) {
                 const int kk = tid / B_CPR + it * B_RPP, cn = (tid % B_CPR) * 4;
                 const int k = kt * KT + kk;
-                const int rem = k % (p.H * p.W);
-                const int yy = rem / p.W + dy, xx = rem % p.W + dx;
+                const int yy = by[it] + dy, xx = bx[it] + dx;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (k < p.K && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && ci0 + cn < p.Cin)
                     v = *reinterpret_cast<const f32x4*>(B + ((long long)k + dy * p.W + dx) * p.ldb + ci0 + cn);
                 rb[it] = v;
+                // advance this row's pixel by KT for the next tile
+                int nx = bx[it] + kinc_x, ny = by[it] + kinc_y;
+                if (nx >= p.W) { nx -= p.W; ++ny; }
+                while (ny >= p.H) ny -= p.H;
+                bx[it] = nx; by[it] = ny;
             }
         }
+        if (AK == VD_IM2COL) { if (++ccA == cchA) { ccA = 0; ++tapA; } }
     };
 
     auto store_tiles = [&](int buf) {
@@ -322,8 +341,11 @@ __global__ void pack_conv3x3_kernel(const float* w, int Cout_w, int Cin_w, float
     }
 }
 
+thread_local int g_last_tile = 0;
+
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    g_last_tile = BM;
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
 }
 
@@ -350,6 +372,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     const int batch = d.batch > 0 ? d.batch : 1;
     const int splitk = d.splitk > 1 ? d.splitk : 1;
     VD_REQUIRE(!(splitk > 1 && batch > 1), "vd_gemm: split-K and batch are exclusive");
+    VD_REQUIRE(!(splitk > 1 && (d.bias || d.R)), "vd_gemm: split-K does not take bias/residual");
 
     GemmArgs a;
     a.A = d.A; a.B = d.B; a.C = d.C; a.bias = d.bias; a.R = d.R;
@@ -409,6 +432,8 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int vd_gemm_last_tile(void) { return g_last_tile; }
 
 extern "C" int vd_gemm(const vd_gemm_desc* d, void* stream) {
     VD_REQUIRE(d != nullptr, "vd_gemm: null descriptor");

@@ -240,14 +240,25 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* part,
     }
 }
 
-// out[c] (+)= sum_b in[b][c]   (two planes at once: dgamma, dbeta)
-__global__ void sum_over_images_kernel(const float* pgb, int nimg, int C, float* dgamma, float* dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= sum_b in[b][c]   (two planes at once: dgamma, dbeta).  Block = 16 channels x 16 lanes over the images,
+// fixed-order LDS tree (deterministic).
+__global__ __launch_bounds__(256) void sum_over_images_kernel(const float* pgb, int nimg, int C, float* dgamma, float* dbeta,
+                                                              int accumulate) {
+    __shared__ float sh[2][16][17];
+    const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     float a = 0.f, bsum = 0.f;
-    for (int b = 0; b < nimg; ++b) { a += pgb[((long long)b * 2) * C + c]; bsum += pgb[((long long)b * 2 + 1) * C + c]; }
-    dgamma[c] = accumulate ? dgamma[c] + a : a;
-    dbeta[c] = accumulate ? dbeta[c] + bsum : bsum;
+    if (c < C)
+        for (int b = ly; b < nimg; b += 16) { a += pgb[((long long)b * 2) * C + c]; bsum += pgb[((long long)b * 2 + 1) * C + c]; }
+    sh[0][ly][cx] = a; sh[1][ly][cx] = bsum;
+    __syncthreads();
+    if (ly == 0 && c < C) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { s0 += sh[0][q][cx]; s1 += sh[1][q][cx]; }
+        dgamma[c] = accumulate ? dgamma[c] + s0 : s0;
+        dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+    }
 }
 
 struct BwdApplyArgs {
@@ -293,12 +304,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const BwdApplyArgs a)
     }
 }
 
-__global__ void colsum_finalize_kernel(const float* part, int chunks, int N, float* out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int chunks, int N, float* out, int accumulate) {
+    __shared__ float sh[16][17];
+    const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + cx;
     float s = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) s += part[(long long)ch * 2 * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int ch = ly; ch < chunks; ch += 16) s += part[(long long)ch * 2 * N + n];
+    sh[ly][cx] = s;
+    __syncthreads();
+    if (ly == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][cx];
+        out[n] = accumulate ? out[n] + t : t;
+    }
 }
 
 inline int pick_cb(int C) {           // channels handled by one reduction block (<= 1024, multiple of 4)
@@ -391,7 +411,7 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
         hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nimg), dim3(256), (2 * C + 2 * G) * sizeof(float), st, part, p.chunks,
                            coef, gamma, beta, film, C, G, HW, q, dfilm, pgb);
         VD_LAUNCH_CHECK("gn_bwd_finalize_kernel");
-        hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 127) / 128), dim3(128), 0, st, pgb, nimg, C, dgamma, dbeta,
+        hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
                            accumulate_params);
         VD_LAUNCH_CHECK("sum_over_images_kernel");
         a.q = q;
@@ -417,7 +437,7 @@ extern "C" int vd_colsum(const float* x, int64_t ldx, int64_t M, int32_t N, floa
     VD_REQUIRE(p.chunks <= 65535 * 32, "vd_colsum: too many rows");
     hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(p.chunks, 1, N / Cb), dim3(256), 0, st, p, Cb);
     VD_LAUNCH_CHECK("chan_reduce_kernel<2>");
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, st, ws, p.chunks, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 15) / 16), dim3(256), 0, st, ws, p.chunks, N, out, accumulate);
     VD_LAUNCH_CHECK("colsum_finalize_kernel");
     return 0;
 }

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "vd_version": (C.c_int, []),
     "vd_last_error": (C.c_char_p, []),
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "vd_gemm_last_tile": (C.c_int, []),
     "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
@@ -111,6 +112,27 @@ def stream():
 
 _ws_cache = {}
 
+# When set to a list, the matmul-shaped wrappers append (kernel_name, flops, start_event, end_event) per launch
+# (bench.py uses it for the live roofline figure; events sit on the stream the kernels are launched on).
+PROFILE = None
+_KIND = {0: "ROW", 1: "COL", 2: "IM2COL"}
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None and exc[0] is None:
+            self.e1.record()
+            PROFILE.append((self.name.format(tile=lib().vd_gemm_last_tile()), self.flops, self.e0, self.e1))
+
 
 def workspace(nbytes, device, tag="default"):
     """Per-(device, stream, tag) scratch buffer, grown on demand.  Kernels on one stream are ordered, so a scratch
@@ -137,19 +159,23 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     if splitk > 1:
         ws = workspace(splitk * M * N * 4, A.device, "splitk")
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
+    with _Timed("gemm_kernel<{tile},{tile}," + f"{_KIND[a_kind]},{_KIND[b_kind]}," + ("splitk>" if splitk > 1 else "direct>"),
+                2.0 * M * N * K * batch):
+        _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False):
-    _check(lib().vd_conv3x3(ptr(x), ldx, ptr(wpack), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
-                            int(accumulate), stream()), "vd_conv3x3")
+    with _Timed("gemm_kernel<{tile},{tile},IM2COL,ROW,direct>", 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3(ptr(x), ldx, ptr(wpack), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
+                                int(accumulate), stream()), "vd_conv3x3")
 
 
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False):
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
-    _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), Cin_w, Cout_w,
-                                  int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
+    with _Timed("gemm_kernel<{tile},{tile},COL,IM2COL,splitk>+reduce", 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), Cin_w, Cout_w,
+                                      int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
 
 
 def pack_conv3x3(w, Cout_w, Cin_w, wf=None, Cin_p=0, wd=None, Cout_p=0):

@@ -438,10 +438,12 @@ class UNetEngine:
     def new_grads(self):
         return {k: torch.empty_like(p) for k, p in self.m.named_parameters()}
 
-    def backward(self, tape, dout, G, need_dx=False):
+    def backward(self, tape, dout, G, need_dx=False, progress=None):
         """dout: NHWC ``[B,H,W,Cp]`` gradient of the padded output (padding channels zero).  Fills ``G`` (name -> tensor,
-        every entry overwritten) and returns d/dx (NCHW) when asked."""
+        every entry overwritten) and returns d/dx (NCHW) when asked.  ``progress(name)`` is called whenever the gradient
+        of ``name`` and of everything before it in trainer.completion_order() is final (gradient-bucket overlap)."""
         m = self.m
+        progress = progress or (lambda name: None)
         B, H0, W0, cop, _ = _chk(dout)
         ta = tape["ta"]
         dta = torch.zeros_like(ta)
@@ -460,6 +462,7 @@ class UNetEngine:
         H.gn_apply_bwd(da, C0, o["h"], _ld(o["h"]), o["coef"], gn.weight, gn.bias, None, 1, 0.0, 0, H.RS_NONE, None, 0, dh, C0,
                        False, None, G["out_conv.0.weight"], G["out_conv.0.bias"], False, B, H0, W0, C0, GROUPS)
         del da
+        progress("out_conv.0.bias")
         # ---- blocks in reverse
         dskip = {}                     # hs id -> gradient view (written by the consuming up-block)
         dh_cur = dh                    # gradient of the running `h`
@@ -487,6 +490,7 @@ class UNetEngine:
                 del dmid
             else:
                 self._res_bwd(b, b.res, b.prefix, tape[b.prefix], dy, dxbuf, acc, dta, G)
+            progress(b.prefix + ".norm.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
             if b.kind == "up" and b.consumes:
                 dh_cur = dxbuf[..., :b.ch_h]
                 dskip[b.src_hs] = dxbuf[..., b.ch_h:]
@@ -499,6 +503,7 @@ class UNetEngine:
         cip = x4.shape[3]
         H.conv3x3_wgrad(x4, cip, dy0, _ld(dy0), B, H0, W0, cip, m.hid_channels, G["in_conv.weight"], m.in_channels, m.hid_channels)
         H.colsum(dy0, _ld(dy0), B * H0 * W0, m.hid_channels, G["in_conv.bias"])
+        progress("in_conv.bias")
         dx = None
         if need_dx:
             d4 = self._new(dout, B, H0, W0, cip)
@@ -509,6 +514,7 @@ class UNetEngine:
             dx = self._new(dout, B, m.in_channels, H0, W0)
             H.nhwc_to_nchw(d4, cip, dx, B, m.in_channels, H0, W0)
         self._embed_bwd(tape["embed"], dta, G)
+        progress(None)
         return dx
 
     def _hs_feeding(self, bi):

@@ -68,11 +68,13 @@ class _UNetFn(torch.autograd.Function):
         cop = (co + 3) // 4 * 4
         d4 = torch.empty((B, Hh, Ww, cop), dtype=torch.float32, device=dout.device)
         _hip.nchw_to_nhwc(dout.to(torch.float32).contiguous(), d4, B, co, Hh, Ww, cop)
+        flat = model._flat_grad_views is not None
         G = model._grad_targets()
-        dx = eng.backward(tape, d4, G, need_dx=ctx.need_dx)
-        hook = getattr(model, "_grads_ready_hook", None)
-        if hook is not None:
-            hook(G)
+        dx = eng.backward(tape, d4, G, need_dx=ctx.need_dx, progress=getattr(model, "_grads_ready_hook", None))
+        if flat:
+            # the kernels already wrote into the caller's flat gradient buffer (trainer.FlatState): autograd gets nothing
+            # to accumulate, which avoids a 243 MB clone per step
+            return (None, dx, None, None) + (None,) * len(G)
         return (None, dx, None, None) + tuple(G[k] for k, _ in model.named_parameters())
 
 

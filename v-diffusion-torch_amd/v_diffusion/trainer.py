@@ -1,0 +1,194 @@
+"""Train-step driver for the hot path: the sequence of reference ``Trainer.loss`` / ``Trainer.step``
+(v_diffusion/train_utils.py:137-169) on flat HBM buffers.
+
+    t ~ U(0,1) fp64, noise ~ N(0,1) from a per-rank generator (seed 8191 + rank)     train_utils.py:124,140-146
+    loss = diffusion.train_loss(model, x, t, y, noise).mean() / num_accum ; backward   :147-154
+    gradient mean over ranks (what DDP does for the reference, train.py:148)           RCCL all-reduce, bucketed
+    clip_grad_norm_(max_norm) -> AdamW -> LR warm-up -> EMA                             :159-168, utils.py:144-149
+
+MI355X-first choices
+  * parameters, gradients, Adam moments and the EMA shadow are each ONE contiguous fp32 buffer (a 60.8 M-parameter CIFAR
+    model is 243 MB per buffer; 288 GB of HBM makes five copies a non-issue).  ``param.data`` / ``param.grad`` are views,
+    so state_dict / checkpoints keep the reference's per-tensor layout.
+  * the weight-gradient kernels write straight into the flat gradient buffer (no per-tensor .grad allocation, no bucket
+    copy); it is laid out in the order the backward pass COMPLETES tensors, so ready gradients always form a prefix and
+    fixed-size buckets can be all-reduced (async, RCCL's own stream) while the rest of backward still runs.  xGMI is
+    point-to-point (7 links x ~153 GB/s): 32 MiB buckets keep each ring step long enough to run at link speed while
+    leaving >= 7 buckets to overlap for the 243 MB CIFAR gradient.
+  * clip + AdamW + EMA is two passes over the flat buffers (sum of squares, then one fused update kernel) instead of
+    the reference's >= 5 foreach passes.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _hip
+
+BUCKET_BYTES = 32 << 20
+
+
+def completion_order(model):
+    """Parameter names in the order ``UNetEngine.backward`` finishes their gradients."""
+    eng = model.engine()
+    names = ["out_conv.2.weight", "out_conv.2.bias", "out_conv.0.weight", "out_conv.0.bias"]
+    have = dict(model.named_parameters())
+
+    def res(p):
+        out = [p + s for s in (".conv2.weight", ".conv2.bias", ".norm2.weight", ".norm2.bias", ".conv1.weight", ".conv1.bias")]
+        if p + ".skip.weight" in have:
+            out += [p + ".skip.weight", p + ".skip.bias"]
+        return out + [p + ".norm1.weight", p + ".norm1.bias", p + ".fc.weight", p + ".fc.bias"]
+
+    def att(p):
+        return [p + s for s in (".proj_out.weight", ".proj_out.bias", ".proj_in.weight", ".proj_in.bias", ".norm.weight", ".norm.bias")]
+
+    for b in reversed(eng.plan):
+        if b.kind == "midattn":
+            names += att(b.prefix)
+        elif b.att is not None:
+            names += att(b.prefix + ".1") + res(b.prefix + ".0")
+        else:
+            names += res(b.prefix)
+    names += ["in_conv.weight", "in_conv.bias"]
+    rest = [k for k in have if k not in set(names)]          # embeddings: finished last
+    names += rest
+    assert sorted(names) == sorted(have), "completion order does not cover the parameter set"
+    return names
+
+
+class FlatState:
+    """Flat fp32 buffers for parameters / gradients / Adam moments / EMA, with per-tensor views."""
+
+    def __init__(self, model, use_ema=True):
+        self.model = model
+        order = completion_order(model)
+        params = dict(model.named_parameters())
+        dev = next(model.parameters()).device
+        offs, n = {}, 0
+        for k in order:
+            offs[k] = n
+            n += (params[k].numel() + 3) // 4 * 4                      # keep every tensor 16-byte aligned
+        self.numel, self.offsets, self.order = n, offs, order
+        self.p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        views = {}
+        with torch.no_grad():
+            for k in order:
+                q = params[k]
+                pv = self.p[offs[k]: offs[k] + q.numel()].view_as(q)
+                pv.copy_(q)
+                q.data = pv                                            # the module now lives in the flat buffer
+                views[k] = self.g[offs[k]: offs[k] + q.numel()].view_as(q)
+        self.grad_views = views
+        model._flat_grad_views = views
+        self.ema = self.p.clone() if use_ema else None
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self.ema_updates = 0
+
+    def ema_state_dict(self):
+        """EMA shadow as a reference-format state_dict (utils.py:168-175 keeps ``shadow`` per parameter name)."""
+        params = dict(self.model.named_parameters())
+        return {k: self.ema[self.offsets[k]: self.offsets[k] + params[k].numel()].view_as(params[k]) for k in self.order}
+
+
+class GradReducer:
+    """Bucketed mean all-reduce of the flat gradient buffer, overlapped with the tail of backward."""
+
+    def __init__(self, flat: FlatState, world_size, bucket_bytes=BUCKET_BYTES, group=None):
+        self.flat, self.world, self.group = flat, world_size, group
+        n, per = flat.numel, max(bucket_bytes // 4, 1)
+        self.bounds = [(a, min(a + per, n)) for a in range(0, n, per)]
+        # first flat offset AFTER each parameter, in completion order -> "ready prefix" length
+        params = dict(flat.model.named_parameters())
+        self.end_of = {k: flat.offsets[k] + params[k].numel() for k in flat.order}
+        self.works, self.next_bucket = [], 0
+
+    def start(self):
+        self.works, self.next_bucket = [], 0
+
+    def _launch(self, lo, hi):
+        t = self.flat.g[lo:hi]
+        self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, name):
+        """Called by the backward pass when ``name`` (and everything before it in completion order) is final."""
+        if self.world == 1:
+            return
+        upto = self.flat.numel if name is None else self.end_of[name]
+        while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][1] <= upto:
+            self._launch(*self.bounds[self.next_bucket])
+            self.next_bucket += 1
+
+    def finish(self):
+        if self.world == 1:
+            return
+        while self.next_bucket < len(self.bounds):
+            self._launch(*self.bounds[self.next_bucket])
+            self.next_bucket += 1
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+class HotPathTrainer:
+    """Equivalent of reference ``Trainer.step`` for one rank (see module docstring)."""
+
+    def __init__(self, model, diffusion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, warmup=5000,
+                 grad_norm=1.0, ema_decay=0.9999, use_ema=True, num_accum=1, timesteps=0, rank=0, world_size=1, group=None):
+        self.model, self.diffusion = model, diffusion
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.warmup, self.grad_norm, self.ema_decay, self.num_accum, self.timesteps = warmup, grad_norm, ema_decay, num_accum, timesteps
+        self.rank, self.world = rank, world_size
+        self.device = next(model.parameters()).device
+        self.flat = FlatState(model, use_ema=use_ema)
+        self.reducer = GradReducer(self.flat, world_size, group=group)
+        model._grads_ready_hook = None
+        self.generator = torch.Generator(self.device).manual_seed(8191 + rank)       # train_utils.py:124
+        if world_size > 1:                                                            # DDP ctor broadcast (train.py:148)
+            dist.broadcast(self.flat.p, src=0, group=group)
+            if self.flat.ema is not None:
+                self.flat.ema.copy_(self.flat.p)
+
+    def draw(self, x):
+        B = x.shape[0]
+        if self.timesteps > 0:
+            t = torch.randint(self.timesteps, size=(B,), dtype=torch.float64, device=self.device,
+                              generator=self.generator).add(1).div(self.timesteps)
+        else:
+            t = torch.rand((B,), dtype=torch.float64, device=self.device, generator=self.generator)
+        noise = torch.empty_like(x).normal_(generator=self.generator)
+        return t, noise
+
+    def step(self, x, y, update=True):
+        """One micro-batch: returns the detached mean loss (device tensor; no host sync here)."""
+        flat = self.flat
+        t, noise = self.draw(x)
+        loss = self.diffusion.train_loss(self.model, x_0=x, t=t, y=y, noise=noise).mean()
+        self.reducer.start()
+        self.model._grads_ready_hook = self.reducer.ready
+        (loss / (self.num_accum * self.world)).backward()          # 1/world folds DDP's gradient averaging into the seed
+        self.model._grads_ready_hook = None
+        self.reducer.finish()
+        if self.num_accum > 1:                                     # the engine overwrites flat.g: keep the running sum
+            if getattr(self, "_acc", None) is None:
+                self._acc = torch.zeros_like(flat.g)
+            self._acc.add_(flat.g)
+            if update:
+                flat.g.copy_(self._acc)
+                self._acc.zero_()
+        if update:
+            flat.step_count += 1
+            k = flat.step_count
+            lr = self.lr * (min(k / self.warmup, 1.0) if self.warmup > 0 else 1.0)    # LambdaLR, train.py:160-162
+            _hip.sumsq(flat.g, flat.gnorm_sq)
+            decay = self.ema_decay
+            if flat.ema is not None:
+                flat.ema_updates += 1
+                decay = min(self.ema_decay, (1 + flat.ema_updates) / (10 + flat.ema_updates))   # utils.py:145-146
+            _hip.adamw_ema(flat.p, flat.g, flat.m, flat.v, flat.ema, flat.gnorm_sq, float(self.grad_norm), lr, self.betas[0],
+                           self.betas[1], self.eps, self.wd, 1 - self.betas[0] ** k, 1 - self.betas[1] ** k, decay)
+        return loss.detach()
