@@ -16,6 +16,7 @@
 //   - all edges are predicated (rows, columns, k, image borders, channel padding), so ragged shapes need no padding
 //     beyond 4-float alignment of the contiguous dimension.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -293,6 +294,246 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (the one that normally runs): tiles go HBM/L2 -> LDS directly with `buffer_load_dwordx4 ... lds`
+// (no VGPR staging, no ds_write pass).  Each wave-instruction writes 1 KiB of LDS linearly (lane x 16 B), so
+//   * k-contiguous operands: one piece = 8 tile rows x 128 B; the XOR chunk swizzle is applied to the per-lane SOURCE
+//     address (lane p of a row fetches chunk p ^ swz(row)), the fragment reads apply the same involution;
+//   * row-contiguous operands: one piece = 1 KiB of consecutive [k][rows] -- already the LDS image.
+// Every edge case is a per-lane offset select: an out-of-range voffset makes the DMA write ZEROS (probed on gfx950:
+// tests/probe/oob.hip), which is exactly the conv zero padding / ragged-tile fill.  Per K tile a thread issues
+// (BM+BN)/32 DMA instructions and a handful of selects; addresses are descriptor-base (SGPR) + constant 32-bit
+// voffset + scalar soffset, so the loop has no 64-bit VALU address math and no branches.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB = 0x80000000u;      // >= num_records of every descriptor below
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)OOB, 0x00020000);
+}
+
+template <int BM, int BN, int AK, int BK, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * KT];
+    constexpr int MT = BM / 64, NT = BN / 64;
+    constexpr int AIT = BM / 32, BIT = BN / 32;          // DMA pieces per wave for A / B
+    constexpr int A_LPR = BM / 4, B_LPR = BN / 4;        // lanes per k-row of a row-contiguous tile
+    constexpr int A_RPP = 64 / A_LPR, B_RPP = 64 / B_LPR;// k-rows per piece
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int m0 = blockIdx.y * BM;
+    int n0 = blockIdx.x * BN;
+    int tapN = 0, ci0 = 0;
+    if (BK == VD_IM2COL) {
+        const int cchN = (p.Cin + BN - 1) / BN;
+        tapN = blockIdx.x / cchN;
+        ci0 = (blockIdx.x % cchN) * BN;
+        n0 = tapN * p.Cin + ci0;
+    }
+    const float* A = p.A;
+    const float* B = p.B;
+    float* C = p.C;
+    const float* R = p.R;
+    int kt_begin = 0, kt_end = p.kt_total;
+    if (SPLITK) {
+        kt_begin = blockIdx.z * p.kt_per_split;
+        kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
+        C += (long long)blockIdx.z * p.slab_stride;
+    } else {
+        const int zb = blockIdx.z / p.nh, zh = blockIdx.z % p.nh;
+        A += zb * p.sAb + zh * p.sAh;
+        B += zb * p.sBb + zh * p.sBh;
+        C += zb * p.sCb + zh * p.sCh;
+        if (R) R += zb * p.sRb + zh * p.sRh;
+    }
+
+    // ---- constant per-thread source offsets (bytes) of every piece this thread takes part in
+    unsigned voA[AIT], voB[BIT];
+    unsigned mkA[AIT];                 // IM2COL A: bit t set <=> tap t of this row is inside the image
+    int kcA[AIT], kcB[BIT];            // k-contiguous tiles: first k (floats) of the 16-byte chunk this lane fetches
+    int by[BIT], bx[BIT];              // IM2COL B: image coordinates of this lane's pixel row
+    const int cchA = (AK == VD_IM2COL) ? (p.Cin + KT - 1) / KT : 1;
+    int tapA = (AK == VD_IM2COL) ? kt_begin / cchA : 0, ccA = (AK == VD_IM2COL) ? kt_begin % cchA : 0;
+    const int kinc_x = (BK == VD_IM2COL) ? KT % p.W : 0, kinc_y = (BK == VD_IM2COL) ? KT / p.W : 0;
+#pragma unroll
+    for (int j = 0; j < AIT; ++j) {
+        const int q = j * 4 + wave;
+        if (AK == VD_COL) {
+            const int kk = q * A_RPP + lane / A_LPR, cm = (lane % A_LPR) * 4;
+            voA[j] = (m0 + cm < p.M) ? (unsigned)(((long long)kk * p.lda + cm) * 4) : OOB;
+            kcA[j] = kk; mkA[j] = 0;
+        } else {
+            const int row = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            kcA[j] = c * 4;
+            voA[j] = (m < p.M) ? (unsigned)(((long long)row * p.lda + c * 4) * 4) : OOB;
+            unsigned mk = 0;
+            if (AK == VD_IM2COL) {
+                const int rem = m % (p.H * p.W), y = rem / p.W, x = rem % p.W;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if ((unsigned)(y + t / 3 - 1) < (unsigned)p.H && (unsigned)(x + t % 3 - 1) < (unsigned)p.W) mk |= 1u << t;
+            }
+            mkA[j] = mk;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BIT; ++j) {
+        const int q = j * 4 + wave;
+        if (BK == VD_ROW) {
+            const int row = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            kcB[j] = c * 4;
+            voB[j] = (n0 + row < p.N) ? (unsigned)(((long long)row * p.ldb + c * 4) * 4) : OOB;
+            by[j] = bx[j] = 0;
+        } else {
+            const int kk = q * B_RPP + lane / B_LPR, cn = (lane % B_LPR) * 4;
+            kcB[j] = kk;
+            const bool ok = (BK == VD_IM2COL) ? (ci0 + cn < p.Cin) : (n0 + cn < p.N);
+            voB[j] = ok ? (unsigned)(((long long)kk * p.ldb + cn) * 4) : OOB;
+            if (BK == VD_IM2COL) {
+                const int k = kt_begin * KT + kk;
+                const int rem = k % (p.H * p.W);
+                by[j] = rem / p.W; bx[j] = rem % p.W;
+            } else by[j] = bx[j] = 0;
+        }
+    }
+    // block-constant parts of the source addresses
+    const float* Ablk = (AK == VD_COL) ? A + m0 : A + (long long)m0 * p.lda;
+    const float* Bblk = (BK == VD_ROW) ? B + (long long)n0 * p.ldb : ((BK == VD_COL) ? B + n0 : B + ci0);
+    const long long tapoffB = (BK == VD_IM2COL) ? (long long)((tapN / 3 - 1) * p.W + (tapN % 3 - 1)) * p.ldb : 0;
+
+    auto dma_tiles = [&](int kt, int buf) {
+        float* as = smem + buf * (BM * KT);
+        float* bs = smem + 2 * BM * KT + buf * (BN * KT);
+        // ------------------------------------------------ A
+        {
+            const int tap = tapA, c0 = ccA * KT;
+            long long aoff;            // floats, block- and tile-constant
+            int kwidth;
+            if (AK == VD_IM2COL) { aoff = (long long)((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.lda + c0; kwidth = p.Cin - c0; }
+            else if (AK == VD_ROW) { aoff = (long long)kt * KT; kwidth = p.K - kt * KT; }
+            else { aoff = (long long)kt * KT * p.lda; kwidth = p.K - kt * KT; }
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Ablk + aoff);
+#pragma unroll
+            for (int j = 0; j < AIT; ++j) {
+                unsigned vo = voA[j];
+                if (kcA[j] >= kwidth) vo = OOB;
+                if (AK == VD_IM2COL && !((mkA[j] >> tap) & 1u)) vo = OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(as + (j * 4 + wave) * 256), 16, (int)vo, 0, 0, 0);
+            }
+        }
+        // ------------------------------------------------ B
+        {
+            long long boff;
+            int kwidth;
+            if (BK == VD_ROW) {
+                if (AK == VD_IM2COL) { boff = (long long)tapA * p.Cin + ccA * KT; kwidth = p.Cin - ccA * KT; }
+                else { boff = (long long)kt * KT; kwidth = p.K - kt * KT; }
+            } else { boff = (long long)kt * KT * p.ldb + tapoffB; kwidth = p.K - kt * KT; }
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Bblk + boff);
+            const int dy = tapN / 3 - 1, dx = tapN % 3 - 1;
+#pragma unroll
+            for (int j = 0; j < BIT; ++j) {
+                unsigned vo = voB[j];
+                if (kcB[j] >= kwidth) vo = OOB;
+                if (BK == VD_IM2COL) {
+                    if ((unsigned)(by[j] + dy) >= (unsigned)p.H || (unsigned)(bx[j] + dx) >= (unsigned)p.W) vo = OOB;
+                    int nx = bx[j] + kinc_x, ny = by[j] + kinc_y;
+                    if (nx >= p.W) { nx -= p.W; ++ny; }
+                    while (ny >= p.H) ny -= p.H;
+                    bx[j] = nx; by[j] = ny;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(bs + (j * 4 + wave) * 256), 16, (int)vo, 0, 0, 0);
+            }
+        }
+        if (AK == VD_IM2COL) { if (++ccA == cchA) { ccA = 0; ++tapA; } }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* as = smem + buf * (BM * KT);
+        const float* bs = smem + 2 * BM * KT + buf * (BN * KT);
+#pragma unroll
+        for (int s = 0; s < KT / 8; ++s) {
+            f32x4 fa[MT], fb[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = wm + 32 * a + li;
+                if (AK == VD_COL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
+                } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz(row, 2 * s + lh));
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int row = wn + 32 * b + li;
+                if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz(row, 2 * s + lh));
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[b][j] = bs[(8 * s + 4 * lh + j) * BN + row];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    if (kt_begin < kt_end) {
+        dma_tiles(kt_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
+            compute(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int ncol = wn + 32 * b + li;
+        const int n = n0 + ncol;
+        const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
+        if (!nok) continue;
+        const float bv = (!SPLITK && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[a][b][r];
+                if (!SPLITK) {
+                    v = v * p.alpha + bv;
+                    if (R) v += R[(long long)m * p.ldr + n];
+                    if (p.accumulate) v += C[(long long)m * p.ldc + n];
+                }
+                C[(long long)m * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
 // out (+)= sum over slabs; optional OIHW transposition for the conv weight gradient
 __global__ void reduce_slabs_kernel(const float* slabs, int S, long long slab_stride, int M, int N, float* out,
                                     long long ldo, int accumulate, float alpha) {
@@ -343,10 +584,19 @@ __global__ void pack_conv3x3_kernel(const float* w, int Cout_w, int Cin_w, float
 
 thread_local int g_last_tile = 0;
 
+bool use_dma(const GemmArgs& a) {
+    static const bool legacy = getenv("VD_GEMM_LEGACY") != nullptr;       // A/B switch for profiling
+    if (legacy) return false;
+    // 32-bit byte offsets inside one block tile must stay below the descriptor range
+    const long long lim = 0x70000000LL / 4;
+    return 128LL * a.lda + 128 < lim && 128LL * a.ldb + 128 < lim && vd_aligned16(a.A) && vd_aligned16(a.B);
+}
+
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
     g_last_tile = BM;
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
+    if (use_dma(a)) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
 }
 
 template <int AK, int BK>
@@ -455,14 +705,22 @@ extern "C" int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, con
 }
 
 static int wgrad_split(int nimg, int H, int W, int Cin, int Cout) {
+    // All blocks of the split-K launch do equal work and 2 of them fit a CU, so the launch runs in whole "rounds" of
+    // 512 blocks: pick the slab count that fills an integer number of rounds as exactly as possible (a 756-block launch
+    // takes two rounds for 1.48 rounds of work), while keeping >= 16 K tiles per block.
     const long long kt = ((long long)nimg * H * W + KT - 1) / KT;
-    const int tile = 128;
-    const long long tiles = ((Cout + tile - 1) / tile) * 9LL * ((Cin + tile - 1) / tile);
-    long long s = (768 + tiles - 1) / tiles;          // aim at ~3 blocks per CU
-    if (s > kt / 8) s = kt / 8;                        // keep >= 8 K tiles per slab
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
+    const long long tiles = ((Cout + 127) / 128) * 9LL * ((Cin + 127) / 128);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 64; ++s) {
+        if (s > 1 && kt / s < 16) break;
+        const long long blocks = tiles * s;
+        const long long rounds = (blocks + 511) / 512;
+        double eff = (double)blocks / (double)(rounds * 512);
+        eff *= 1.0 - 0.004 * s;                       // mild preference for fewer slabs (less reduce traffic)
+        if (eff > best_eff) { best_eff = eff; best = s; }
+    }
+    return best;
 }
 
 extern "C" size_t vd_conv3x3_wgrad_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {

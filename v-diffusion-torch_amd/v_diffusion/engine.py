@@ -40,7 +40,7 @@ def _chk(t):
 def _splitk(M, N, K):
     """split-K factor for the small-output weight-gradient GEMMs (K = batch*pixels)."""
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    s = max(1, min(64, 512 // max(tiles, 1), K // 256))
+    s = max(1, min(64, 1024 // max(tiles, 1), K // 256))
     return s
 
 
