@@ -113,7 +113,8 @@ def stream():
 _ws_cache = {}
 
 # When set to a list, the matmul-shaped wrappers append (kernel_name, flops, start_event, end_event) per launch
-# (bench.py uses it for the live roofline figure; events sit on the stream the kernels are launched on).
+# (bench.py uses it for the live roofline figure; events sit on the stream the kernels are launched on).  Names are the
+# rocprofv3 kernel names: gemm_dma_kernel<BM, BN, a_kind, b_kind, splitk> with kinds 0 = ROW, 1 = COL, 2 = IM2COL.
 PROFILE = None
 _KIND = {0: "ROW", 1: "COL", 2: "IM2COL"}
 
@@ -159,13 +160,13 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     if splitk > 1:
         ws = workspace(splitk * M * N * 4, A.device, "splitk")
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    with _Timed("gemm_kernel<{tile},{tile}," + f"{_KIND[a_kind]},{_KIND[b_kind]}," + ("splitk>" if splitk > 1 else "direct>"),
+    with _Timed("gemm_dma_kernel<{tile}, {tile}, " + f"{a_kind}, {b_kind}, " + ("true>" if splitk > 1 else "false>"),
                 2.0 * M * N * K * batch):
         _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False):
-    with _Timed("gemm_kernel<{tile},{tile},IM2COL,ROW,direct>", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _Timed("gemm_dma_kernel<{tile}, {tile}, 2, 0, false>", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3(ptr(x), ldx, ptr(wpack), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
                                 int(accumulate), stream()), "vd_conv3x3")
 
@@ -173,7 +174,7 @@ def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False):
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
-    with _Timed("gemm_kernel<{tile},{tile},COL,IM2COL,splitk>+reduce", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _Timed("gemm_dma_kernel<{tile}, {tile}, 1, 2, true> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), Cin_w, Cout_w,
                                       int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
 
