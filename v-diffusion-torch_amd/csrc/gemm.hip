@@ -91,8 +91,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int cchA = (AK == VD_IM2COL) ? (p.Cin + KT - 1) / KT : 1;
     // K-tile cursor of the im2col A operand: (tap, channel chunk), advanced once per load_tiles call (tiles are
     // visited in order), so the main loop has no integer division
-    int tapA = (AK == VD_IM2COL) ? kt_begin / cchA : 0;
-    int ccA = (AK == VD_IM2COL) ? kt_begin % cchA : 0;
+    // (taps are the FAST index: the 9 shifted reads of one 32-channel slab are adjacent in time and hit L1/L2)
+    int tapA = (AK == VD_IM2COL) ? kt_begin % 9 : 0;
+    int ccA = (AK == VD_IM2COL) ? kt_begin / 9 : 0;
     // pixel cursor of the im2col B operand (wgrad): image coordinates of this thread's k rows
     int by[BIT], bx[BIT];
     const int kinc_x = (BK == VD_IM2COL) ? KT % p.W : 0, kinc_y = (BK == VD_IM2COL) ? KT / p.W : 0;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 bx[it] = nx; by[it] = ny;
             }
         }
-        if (AK == VD_IM2COL) { if (++ccA == cchA) { ccA = 0; ++tapA; } }
+        if (AK == VD_IM2COL) { if (++tapA == 9) { tapA = 0; ++ccA; } }
     };
 
     auto store_tiles = [&](int buf) {
@@ -312,13 +313,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)OOB, 0x00020000);
 }
 
-template <int BM, int BN, int AK, int BK, bool SPLITK>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p) {
+// k-contiguous LDS image: [row][KT] floats, 16-byte chunk index XOR-swizzled so that a ds_read_b128 of 32 consecutive
+// rows at one chunk is bank-conflict free (KT = 32: 8 chunks/row, swizzle (row>>1)&7; KT = 16: 4 chunks/row, (row>>2)&3)
+template <int KT>
+__device__ __forceinline__ int swz_of(int row) { return KT == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int KT>
+__device__ __forceinline__ int row_swz_t(int row, int chunk) { return row * KT + ((chunk ^ swz_of<KT>(row)) << 2); }
+
+// KT = K tile.  128x128 tiles use KT = 16: 32 KB of LDS per workgroup -> 4 workgroups (4 waves per SIMD) per CU, which
+// fills the MFMA issue slots a barrier-parked wave leaves empty (PMC: 2 waves/SIMD left the matrix pipe 14.5 % idle).
+template <int BM, int BN, int AK, int BK, bool SPLITK, int KT>
+__global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * KT];
     constexpr int MT = BM / 64, NT = BN / 64;
-    constexpr int AIT = BM / 32, BIT = BN / 32;          // DMA pieces per wave for A / B
+    constexpr int AIT = BM * KT / 1024, BIT = BN * KT / 1024;   // DMA pieces (1 KiB) per wave for A / B
     constexpr int A_LPR = BM / 4, B_LPR = BN / 4;        // lanes per k-row of a row-contiguous tile
     constexpr int A_RPP = 64 / A_LPR, B_RPP = 64 / B_LPR;// k-rows per piece
+    constexpr int RLPR = KT / 4, RRPP = 64 / RLPR;       // k-contiguous tile: lanes per row, rows per piece
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -356,7 +367,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p) {
     int kcA[AIT], kcB[BIT];            // k-contiguous tiles: first k (floats) of the 16-byte chunk this lane fetches
     int by[BIT], bx[BIT];              // IM2COL B: image coordinates of this lane's pixel row
     const int cchA = (AK == VD_IM2COL) ? (p.Cin + KT - 1) / KT : 1;
-    int tapA = (AK == VD_IM2COL) ? kt_begin / cchA : 0, ccA = (AK == VD_IM2COL) ? kt_begin % cchA : 0;
+    // K tiles of the im2col A operand are ordered (channel slab, tap) with the TAP as the fast index: the nine shifted
+    // reads of one 32-channel slab of the block's pixel window are adjacent in time, so eight of them hit L1/L2 instead of
+    // going back to the fabric (rocprof FETCH_SIZE of the 256->256 @32x32 conv: see profiles/)
+    int tapA = (AK == VD_IM2COL) ? kt_begin % 9 : 0, ccA = (AK == VD_IM2COL) ? kt_begin / 9 : 0;
     const int kinc_x = (BK == VD_IM2COL) ? KT % p.W : 0, kinc_y = (BK == VD_IM2COL) ? KT / p.W : 0;
 #pragma unroll
     for (int j = 0; j < AIT; ++j) {
@@ -366,8 +380,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p) {
             voA[j] = (m0 + cm < p.M) ? (unsigned)(((long long)kk * p.lda + cm) * 4) : OOB;
             kcA[j] = kk; mkA[j] = 0;
         } else {
-            const int row = q * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int row = q * RRPP + lane / RLPR;
+            const int c = (lane % RLPR) ^ swz_of<KT>(row);
             const int m = m0 + row;
             kcA[j] = c * 4;
             voA[j] = (m < p.M) ? (unsigned)(((long long)row * p.lda + c * 4) * 4) : OOB;
@@ -385,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p) {
     for (int j = 0; j < BIT; ++j) {
         const int q = j * 4 + wave;
         if (BK == VD_ROW) {
-            const int row = q * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int row = q * RRPP + lane / RLPR;
+            const int c = (lane % RLPR) ^ swz_of<KT>(row);
             kcB[j] = c * 4;
             voB[j] = (n0 + row < p.N) ? (unsigned)(((long long)row * p.ldb + c * 4) * 4) : OOB;
             by[j] = bx[j] = 0;
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(bs + (j * 4 + wave) * 256), 16, (int)vo, 0, 0, 0);
             }
         }
-        if (AK == VD_IM2COL) { if (++ccA == cchA) { ccA = 0; ++tapA; } }
+        if (AK == VD_IM2COL) { if (++tapA == 9) { tapA = 0; ++ccA; } }
     };
 
     f32x16 acc[MT][NT];
@@ -474,12 +488,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs p) {
                 if (AK == VD_COL) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
-                } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz(row, 2 * s + lh));
+                } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 2 * s + lh));
             }
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 const int row = wn + 32 * b + li;
-                if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz(row, 2 * s + lh));
+                if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz_t<KT>(row, 2 * s + lh));
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fb[b][j] = bs[(8 * s + 4 * lh + j) * BN + row];
@@ -583,6 +597,7 @@ __global__ void pack_conv3x3_kernel(const float* w, int Cout_w, int Cin_w, float
 }
 
 thread_local int g_last_tile = 0;
+thread_local int g_last_slabs = 1;     // slabs the last split-K launch really wrote
 
 bool use_dma(const GemmArgs& a) {
     static const bool legacy = getenv("VD_GEMM_LEGACY") != nullptr;       // A/B switch for profiling
@@ -592,17 +607,28 @@ bool use_dma(const GemmArgs& a) {
     return 128LL * a.lda + 128 < lim && 128LL * a.ldb + 128 < lim && vd_aligned16(a.A) && vd_aligned16(a.B);
 }
 
+// K tile of the kernel that will run.  The 128x128 LDS-DMA kernel exists with KT = 32 (64 KB LDS, 2 workgroups per CU)
+// and KT = 16 (32 KB, 5 per CU): the deeper occupancy wins (+2-3 %) only when the launch has enough workgroups to
+// give every CU five of them; short launches and the split-K weight gradient keep the longer K tile.
+inline int ktile_for(const GemmArgs& a, int tile, long long nblocks, bool splitk) {
+    static const char* force = getenv("VD_GEMM_KT");
+    if (tile != 128 || !use_dma(a)) return KT;
+    if (force) return atoi(force) == 16 ? 16 : 32;
+    return (!splitk && nblocks >= 2048) ? 16 : 32;
+}
+
 template <int BM, int BN, int AK, int BK, bool SPLITK>
-void launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
+void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     g_last_tile = BM;
-    if (use_dma(a)) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
+    if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
+    else if (BM == 128 && ktile == 16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (BM == 128 ? 16 : 32)>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32>), grid, dim3(256), 0, st, a);
 }
 
 template <int AK, int BK>
-void launch_tile(int tile, bool splitk, const GemmArgs& a, dim3 grid, hipStream_t st) {
-    if (tile == 128) { if (splitk) launch<128, 128, AK, BK, true>(a, grid, st); else launch<128, 128, AK, BK, false>(a, grid, st); }
-    else             { if (splitk) launch<64, 64, AK, BK, true>(a, grid, st);   else launch<64, 64, AK, BK, false>(a, grid, st); }
+void launch_tile(int tile, bool splitk, const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
+    if (tile == 128) { if (splitk) launch<128, 128, AK, BK, true>(a, grid, st, ktile); else launch<128, 128, AK, BK, false>(a, grid, st, ktile); }
+    else             { if (splitk) launch<64, 64, AK, BK, true>(a, grid, st, ktile);   else launch<64, 64, AK, BK, false>(a, grid, st, ktile); }
 }
 
 int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
@@ -632,8 +658,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.sAb = d.sAb; a.sAh = d.sAh; a.sBb = d.sBb; a.sBh = d.sBh; a.sCb = d.sCb; a.sCh = d.sCh; a.sRb = d.sRb; a.sRh = d.sRh;
     a.alpha = d.alpha; a.accumulate = d.accumulate;
     a.H = d.H; a.W = d.W; a.Cin = d.Cin;
-    a.kt_total = conv ? 9 * ((d.Cin + KT - 1) / KT) : (d.K + KT - 1) / KT;
-    a.kt_per_split = a.kt_total; a.slab_stride = 0;
+    a.kt_total = 0; a.kt_per_split = 0; a.slab_stride = 0;
 
     // tile choice: 128x128 when that still gives >= 1.5 blocks per CU, else 64x64
     auto ntiles = [&](int t) {
@@ -646,19 +671,23 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     const long long nm = (d.M + tile - 1) / tile;
     const long long nn = wgrad ? 9LL * ((d.Cin + tile - 1) / tile) : (d.N + tile - 1) / tile;
     VD_REQUIRE(nm <= 65535, "vd_gemm: too many row tiles (%lld)", nm);
+    const int ktile = ktile_for(a, tile, nm * nn * batch, splitk > 1);
+    a.kt_total = conv ? 9 * ((d.Cin + ktile - 1) / ktile) : (d.K + ktile - 1) / ktile;
+    a.kt_per_split = a.kt_total;
 
     float* final_C = d.C;
     if (splitk > 1) {
         a.kt_per_split = (a.kt_total + splitk - 1) / splitk;
         const int used = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;
+        g_last_slabs = used;
         a.slab_stride = (long long)d.M * d.N;
         VD_REQUIRE(d.ws && d.ws_bytes >= (int64_t)(used * a.slab_stride * 4), "vd_gemm: split-K workspace too small");
         a.C = d.ws; a.ldc = d.N;
         dim3 grid(nn, nm, used);
-        if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, true, a, grid, st);
-        else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, true, a, grid, st);
-        else if (ak == VD_ROW && bk == VD_ROW) launch_tile<VD_ROW, VD_ROW>(tile, true, a, grid, st);
-        else if (ak == VD_ROW && bk == VD_COL) launch_tile<VD_ROW, VD_COL>(tile, true, a, grid, st);
+        if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, true, a, grid, st, ktile);
+        else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, true, a, grid, st, ktile);
+        else if (ak == VD_ROW && bk == VD_ROW) launch_tile<VD_ROW, VD_ROW>(tile, true, a, grid, st, ktile);
+        else if (ak == VD_ROW && bk == VD_COL) launch_tile<VD_ROW, VD_COL>(tile, true, a, grid, st, ktile);
         else VD_REQUIRE(false, "vd_gemm: split-K not built for kinds (%d,%d)", ak, bk);
         VD_LAUNCH_CHECK("gemm_kernel(splitk)");
         if (!wgrad) {   // plain reduce here; the conv wgrad caller reduces with the OIHW transposition itself
@@ -670,12 +699,12 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
         return 0;
     }
     dim3 grid(nn, nm, batch);
-    if (ak == VD_ROW && bk == VD_ROW) launch_tile<VD_ROW, VD_ROW>(tile, false, a, grid, st);
-    else if (ak == VD_ROW && bk == VD_COL) launch_tile<VD_ROW, VD_COL>(tile, false, a, grid, st);
-    else if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, false, a, grid, st);
-    else if (ak == VD_COL && bk == VD_ROW) launch_tile<VD_COL, VD_ROW>(tile, false, a, grid, st);
-    else if (ak == VD_IM2COL && bk == VD_ROW) launch_tile<VD_IM2COL, VD_ROW>(tile, false, a, grid, st);
-    else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, false, a, grid, st);
+    if (ak == VD_ROW && bk == VD_ROW) launch_tile<VD_ROW, VD_ROW>(tile, false, a, grid, st, ktile);
+    else if (ak == VD_ROW && bk == VD_COL) launch_tile<VD_ROW, VD_COL>(tile, false, a, grid, st, ktile);
+    else if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, false, a, grid, st, ktile);
+    else if (ak == VD_COL && bk == VD_ROW) launch_tile<VD_COL, VD_ROW>(tile, false, a, grid, st, ktile);
+    else if (ak == VD_IM2COL && bk == VD_ROW) launch_tile<VD_IM2COL, VD_ROW>(tile, false, a, grid, st, ktile);
+    else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, false, a, grid, st, ktile);
     else VD_REQUIRE(false, "vd_gemm: unsupported operand kinds (%d,%d)", ak, bk);
     VD_LAUNCH_CHECK("gemm_kernel");
     return 0;
@@ -705,18 +734,19 @@ extern "C" int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, con
 }
 
 static int wgrad_split(int nimg, int H, int W, int Cin, int Cout) {
-    // All blocks of the split-K launch do equal work and 2 of them fit a CU, so the launch runs in whole "rounds" of
-    // 512 blocks: pick the slab count that fills an integer number of rounds as exactly as possible (a 756-block launch
-    // takes two rounds for 1.48 rounds of work), while keeping >= 16 K tiles per block.
-    const long long kt = ((long long)nimg * H * W + KT - 1) / KT;
+    // All blocks of the split-K launch do equal work and 2 of them fit a CU (KT = 32 kernel, 64 KB LDS), so the launch
+    // runs in "rounds" of 512 resident blocks: pick the slab count that fills whole rounds as exactly as possible (a
+    // 756-block launch took two rounds for 1.48 rounds of work), keeping >= 512 pixels of K per slab.
+    const long long kt = ((long long)nimg * H * W + 31) / 32;
     const long long tiles = ((Cout + 127) / 128) * 9LL * ((Cin + 127) / 128);
+    const long long slots = 512;
     int best = 1;
     double best_eff = 0.0;
     for (int s = 1; s <= 64; ++s) {
         if (s > 1 && kt / s < 16) break;
         const long long blocks = tiles * s;
-        const long long rounds = (blocks + 511) / 512;
-        double eff = (double)blocks / (double)(rounds * 512);
+        const long long rounds = (blocks + slots - 1) / slots;
+        double eff = (double)blocks / (double)(rounds * slots);
         eff *= 1.0 - 0.004 * s;                       // mild preference for fewer slabs (less reduce traffic)
         if (eff > best_eff) { best_eff = eff; best = s; }
     }
@@ -748,8 +778,7 @@ extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, 
     if (S > 1) {
         int rc = run_gemm(d, st);
         if (rc) return rc;
-        const long long kt = ((long long)d.K + KT - 1) / KT, per = (kt + S - 1) / S;
-        used = (int)((kt + per - 1) / per);
+        used = g_last_slabs;
     } else {
         d.splitk = 1;
         int rc = run_gemm(d, st);
