@@ -33,12 +33,18 @@ PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 CIFAR = dict(in_channels=3, hid_channels=256, out_channels=3, ch_multipliers=[1, 1, 1], num_res_blocks=3,
              apply_attn=[False, True, True], drop_rate=0.2, num_heads=1, num_classes=10, multitags=False)
 FWD_GFLOP_PER_IMG = 37.64              # matmul-class FLOPs of one CIFAR UNet forward
+# configs/celeba.json merged with defaults.json (num_heads=1) and --model-out-type v (BASELINE configs[3], parity-test /
+# secondary workload: `--config celeba`)
+CELEBA = dict(in_channels=3, hid_channels=192, out_channels=3, ch_multipliers=[1, 2, 3, 4], num_res_blocks=3,
+              apply_attn=[False, True, True, True], embedding_dim=768, drop_rate=0.1, head_dim=64, num_heads=1,
+              num_classes=40, multitags=True)
+CELEBA_FWD_GFLOP_PER_IMG = 201.3
 
 
-def build_model(device, seed=1234):
+def build_model(device, seed=1234, cfg=None):
     import v_diffusion
     torch.manual_seed(seed)
-    model = v_diffusion.UNet(**CIFAR)
+    model = v_diffusion.UNet(**(cfg or CIFAR))
     with torch.no_grad():                 # re-randomise the zero-initialised tensors
         for name, p in model.named_parameters():
             if p.ndim >= 2 and float(p.abs().max()) == 0.0:
@@ -106,7 +112,13 @@ def main():
     ap.add_argument("--no-sample", action="store_true", help="skip the DDIM-50 CFG sampling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-steps", type=int, default=50)
+    ap.add_argument("--config", choices=["cifar10", "celeba"], default="cifar10",
+                    help="cifar10 = the headline workload (BASELINE configs[1]); celeba = configs[3], secondary")
     args = ap.parse_args()
+    celeba = args.config == "celeba"
+    global FWD_GFLOP_PER_IMG
+    if celeba:
+        FWD_GFLOP_PER_IMG = CELEBA_FWD_GFLOP_PER_IMG
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,16 +137,20 @@ def main():
     from v_diffusion.trainer import HotPathTrainer
     _hip.lib()
 
-    model = build_model(device)
+    model = build_model(device, cfg=CELEBA if celeba else CIFAR)
     model.train()
     diffusion = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), args.sample_steps, "v",
                                               "fixed_medium", "snr_trunc", "mse", intp_frac=0.3, w_guide=1.0, p_uncond=0.1)
     trainer = HotPathTrainer(model, diffusion, lr=2e-4, weight_decay=0.001, warmup=1000, grad_norm=1.0, ema_decay=0.9999,
                              use_ema=True, rank=rank, world_size=world)
     B = args.batch
+    RES = 64 if celeba else 32
     g = torch.Generator(device).manual_seed(4321 + rank)
-    x = torch.rand((B, 3, 32, 32), device=device, generator=g) * 2 - 1                    # Normalize(0.5, 0.5) range
-    labels = torch.randint(1, 11, (B,), device=device, generator=g).float()                # target_transform y+1
+    x = torch.rand((B, 3, RES, RES), device=device, generator=g) * 2 - 1                  # Normalize(0.5, 0.5) range
+    if celeba:
+        labels = (torch.rand((B, 40), device=device, generator=g) < 0.2).float()           # CelebA attribute tags
+    else:
+        labels = torch.randint(1, 11, (B,), device=device, generator=g).float()            # target_transform y+1
 
     def barrier():
         if world > 1:
@@ -189,11 +205,11 @@ def main():
     if not args.no_sample:
         model.eval()
         SB = B
-        lab = torch.randint(1, 11, (SB,), device=device, generator=g).float()
-        diffusion.p_sample(model, (8, 3, 32, 32), label=lab[:8], device=device, seed=131071 + rank, use_ddim=True)   # warm-up
+        lab = labels[:SB].clone()
+        diffusion.p_sample(model, (8, 3, RES, RES), label=lab[:8], device=device, seed=131071 + rank, use_ddim=True)   # warm-up
         barrier()
         t0 = time.perf_counter()
-        out = diffusion.p_sample(model, (SB, 3, 32, 32), label=lab, device=device, seed=131071 + rank, use_ddim=True)
+        out = diffusion.p_sample(model, (SB, 3, RES, RES), label=lab, device=device, seed=131071 + rank, use_ddim=True)
         barrier()
         ds = time.perf_counter() - t0
         if world > 1:
@@ -216,9 +232,10 @@ def main():
         line = {"metric": "train_images_per_sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-                "config": {"workload": "CIFAR-10 32x32 class-cond v-pred UNet (cifar10_cond.json, 60.8M params) full train step: "
+                "config": {"workload": ("CelebA 64x64 multitag v-pred UNet (celeba.json+defaults.json, 266.8M params)" if celeba else
+                                        "CIFAR-10 32x32 class-cond v-pred UNet (cifar10_cond.json, 60.8M params)") + " full train step: "
                                        "q_sample+fwd+snr_trunc v-loss+bwd+grad all-reduce+clip+AdamW+EMA; second figure: DDIM-50 CFG w=1 sampling",
-                           "global_batch": world * B, "per_gpu_batch": B, "resolution": 32, "parallelism": f"dp{world}",
+                           "global_batch": world * B, "per_gpu_batch": B, "resolution": RES, "parallelism": f"dp{world}",
                            "final_loss": round(final_loss, 5)},
                 "frac_of_fp32_mfma_peak_whole_step": round(3 * FWD_GFLOP_PER_IMG * B / (ms_per_step * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "roofline": roofline, "cpu_baseline": cpu, "sampling": sampling}

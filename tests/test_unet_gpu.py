@@ -248,3 +248,47 @@ def test_p_sample_trajectories_vs_golden(vd, golden_dir):
     assert float(preds.abs().max()) <= 3.0 + 1e-5                              # clipped x0 per branch, w=1: |c + (c - u)| <= 3
     _, p4 = gd.p_sample_progressive(model, shape, label=y, device=DEV, seed=11, use_ddim=True, pred_freq=4)
     assert p4.shape == (2, B, 3, R, R) and torch.equal(p4[0], preds[3]) and torch.equal(p4[1], preds[7])
+
+
+# ------------------------------------------------------------------------------------------------ flat-buffer trainer
+def test_hot_path_trainer_matches_torch_optimizer(vd):
+    """HotPathTrainer.step (flat buffers, fused clip+AdamW+EMA kernel) == the reference's Trainer.step sequence
+    (train_utils.py:151-169: clip_grad_norm_ -> AdamW -> LambdaLR warm-up -> EMA) run with torch on the same gradients."""
+    import copy
+    from oracle.cases import TINY, make_inputs
+    from v_diffusion.trainer import HotPathTrainer
+    # tinyC has 2 channels per GroupNorm group: with 1 channel per group (tinyA/B) the conv biases in front of a norm have
+    # an exactly-zero gradient, i.e. pure rounding noise, which Adam's g/sqrt(v) would amplify to +-lr in both runs
+    case = TINY["tinyC"]
+    cfg = case["cfg"]
+    model, _ = _build(vd, cfg, train=True)
+    ref = copy.deepcopy(model)
+    gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine"), 8, "v", "fixed_large", "snr_trunc", "mse", p_uncond=0.0)
+    tr = HotPathTrainer(model, gd, lr=1e-3, weight_decay=0.01, warmup=4, grad_norm=0.5, ema_decay=0.9, use_ema=True)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda t: min((t + 1) / 4, 1.0))
+    shadow = {k: p.detach().clone() for k, p in ref.named_parameters()}
+    gen = torch.Generator(DEV).manual_seed(8191)            # the trainer's own stream (train_utils.py:124)
+    x, _, _ = make_inputs(cfg, 4, case["R"], case["label"], seed=5)
+    x = x.clamp(-1, 1).to(DEV)
+    for it in range(3):
+        loss_fast = tr.step(x, None)
+        t = torch.rand((4,), dtype=torch.float64, device=DEV, generator=gen)
+        noise = torch.empty_like(x).normal_(generator=gen)
+        loss = gd.train_loss(ref, x, t, None, noise).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=0.5)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        sched.step()
+        decay = min(0.9, (1 + it + 1) / (10 + it + 1))
+        for k, p in ref.named_parameters():
+            shadow[k] += (1 - decay) * (p.detach() - shadow[k])
+        assert abs(float(loss_fast) - float(loss)) <= 1e-5 * max(abs(float(loss)), 1.0)
+    ema = tr.flat.ema_state_dict()
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert (p - q).abs().max().item() <= 2e-5 * max(q.abs().max().item(), 1e-3), k
+        assert (ema[k] - shadow[k]).abs().max().item() <= 2e-5 * max(q.abs().max().item(), 1e-3), k
+    # the module still round-trips through state_dict in the reference layout
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ref.state_dict().keys())
