@@ -54,14 +54,14 @@ typedef struct vd_gemm_desc {
     int32_t H, W, Cin;          /* image geometry for VD_IM2COL                                     */
     int32_t splitk;             /* >1: K is split over `splitk` slabs in ws, then reduced into C    */
     float*  ws; int64_t ws_bytes;
-    int32_t tile;               /* 0 = auto, 128 or 64 forces the block tile                        */
+    int32_t tile;               /* 0 = auto; 128, 64, 12864 (128x64), 64128 (64x128) force the block tile */
 } vd_gemm_desc;
 
 /* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two
  * einsum contractions of attention (unet.py:57,61-63) and all of their autograd backward GEMMs */
 int vd_gemm(const vd_gemm_desc* d, void* stream);
-/* block tile (128 or 64) the calling thread's last vd_gemm / vd_conv3x3* launch used (profiling aid: names the kernel
- * instantiation gemm_kernel<tile,tile,a_kind,b_kind,splitk> a launch went to) */
+/* block tile BM*1000+BN the calling thread's last vd_gemm / vd_conv3x3* launch used (profiling aid: names the kernel
+ * instantiation gemm_dma_kernel<BM,BN,a_kind,b_kind,splitk,KT> a launch went to) */
 int vd_gemm_last_tile(void);
 
 /* 3x3 / stride 1 / pad 1 convolution, NHWC (replaces F.conv2d at modules.py:141-144 <- unet.py:121,125,217,232).

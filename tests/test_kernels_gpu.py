@@ -44,7 +44,7 @@ GEMM_SHAPES = [(128, 128, 32), (64, 64, 64), (200, 72, 100), (256, 512, 1024), (
 
 @pytest.mark.parametrize("a_kind,b_kind", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("tile", [0, 64, 128, 12864, 64128])
 def test_gemm_kinds(H, a_kind, b_kind, M, N, K, tile):
     A = rnd(M, K, seed=1)
     B = rnd(N, K, seed=2)
@@ -114,6 +114,7 @@ def from_nhwc(y, Cc):
 
 
 CONV_CASES = [  # nimg, H, W, Cin, Cout, ldx_extra, ldy_extra
+    (4, 32, 32, 192, 192, 0, 0), (2, 16, 16, 576, 320, 0, 0), (64, 16, 16, 64, 192, 0, 0),
     (2, 8, 8, 32, 64, 0, 0), (3, 16, 16, 64, 32, 32, 64), (1, 32, 32, 256, 256, 0, 0), (2, 16, 16, 4, 32, 0, 0),
     (2, 8, 8, 32, 3, 0, 1), (2, 4, 4, 96, 160, 0, 0), (5, 8, 8, 36, 68, 4, 4), (1, 2, 2, 8, 8, 0, 0), (2, 64, 64, 32, 32, 0, 0)]
 
@@ -156,7 +157,8 @@ def test_conv3x3_dgrad(H, case):
     close(from_nhwc(dx, Cin), x.grad, x32.grad, name="conv dgrad")
 
 
-@pytest.mark.parametrize("case", [(2, 8, 8, 32, 64, 32, 64), (4, 16, 16, 64, 32, 64, 32), (2, 32, 32, 256, 256, 256, 256),
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 64, 32, 64), (4, 16, 16, 64, 32, 64, 32), (4, 32, 32, 192, 192, 192, 192),
+                                  (2, 16, 16, 576, 192, 576, 192), (2, 16, 16, 192, 384, 192, 384), (2, 32, 32, 256, 256, 256, 256),
                                   (3, 16, 16, 4, 32, 3, 32), (3, 8, 8, 32, 4, 32, 3), (8, 32, 32, 32, 32, 32, 32)])
 def test_conv3x3_wgrad(H, case):
     nimg, Hh, Ww, Cin, Cout, Cin_w, Cout_w = case

@@ -16,6 +16,7 @@
 //   - all edges are predicated (rows, columns, k, image borders, channel padding), so ragged shapes need no padding
 //     beyond 4-float alignment of the contiguous dimension.
 #include "common.h"
+#include <math.h>
 #include <stdlib.h>
 
 namespace {
@@ -607,28 +608,61 @@ bool use_dma(const GemmArgs& a) {
     return 128LL * a.lda + 128 < lim && 128LL * a.ldb + 128 < lim && vd_aligned16(a.A) && vd_aligned16(a.B);
 }
 
+// ---- block-tile menu.  Rectangular tiles exist for channel counts that are not multiples of 128 (CelebA: 192, 576, 960,
+// 1344): a 192-wide N on 128-wide tiles would burn 25 % of the MFMA work on zero padding.
+struct TileCfg { int bm, bn; double eff; int per_cu; };
+const TileCfg TILES[4] = {{128, 128, 1.00, 2}, {128, 64, 0.92, 3}, {64, 128, 0.92, 3}, {64, 64, 0.80, 5}};
+
+// cheapest tile = least (padded MFMA work / per-tile efficiency), with a penalty when the launch cannot give every CU
+// at least two workgroups
+int choose_tile(long long M, long long Ncols, bool wgrad, long long zcount, int forced) {
+    if (forced == 128) return 0;
+    if (forced == 12864) return 1;
+    if (forced == 64128) return 2;
+    if (forced == 64) return 3;
+    int best = 0;
+    double best_cost = 1e300;
+    for (int t = 0; t < 4; ++t) {
+        const long long nm = (M + TILES[t].bm - 1) / TILES[t].bm, nn = (Ncols + TILES[t].bn - 1) / TILES[t].bn;
+        const double blocks = (double)nm * nn * (wgrad ? 9 : 1) * zcount;
+        double cost = (double)(nm * TILES[t].bm) * (double)(nn * TILES[t].bn) / TILES[t].eff;
+        if (blocks < 512.0) cost *= sqrt(512.0 / blocks);
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
+}
+
 // K tile of the kernel that will run.  The 128x128 LDS-DMA kernel exists with KT = 32 (64 KB LDS, 2 workgroups per CU)
 // and KT = 16 (32 KB, 5 per CU): the deeper occupancy wins (+2-3 %) only when the launch has enough workgroups to
 // give every CU five of them; short launches and the split-K weight gradient keep the longer K tile.
-inline int ktile_for(const GemmArgs& a, int tile, long long nblocks, bool splitk) {
+inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk) {
     static const char* force = getenv("VD_GEMM_KT");
-    if (tile != 128 || !use_dma(a)) return KT;
+    if (t != 0 || !use_dma(a)) return KT;
     if (force) return atoi(force) == 16 ? 16 : 32;
     return (!splitk && nblocks >= 2048) ? 16 : 32;
 }
 
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
-    g_last_tile = BM;
+    g_last_tile = BM * 1000 + BN;
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
-    else if (BM == 128 && ktile == 16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (BM == 128 ? 16 : 32)>), grid, dim3(256), 0, st, a);
+    else if (BM == 128 && BN == 128 && ktile == 16)
+        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, ((BM == 128 && BN == 128) ? 16 : 32)>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32>), grid, dim3(256), 0, st, a);
 }
 
+template <int AK, int BK, bool SPLITK>
+void launch_tile2(int t, const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
+    if (t == 0) launch<128, 128, AK, BK, SPLITK>(a, grid, st, ktile);
+    else if (t == 1) launch<128, 64, AK, BK, SPLITK>(a, grid, st, ktile);
+    else if (t == 2) launch<64, 128, AK, BK, SPLITK>(a, grid, st, ktile);
+    else launch<64, 64, AK, BK, SPLITK>(a, grid, st, ktile);
+}
+
 template <int AK, int BK>
-void launch_tile(int tile, bool splitk, const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
-    if (tile == 128) { if (splitk) launch<128, 128, AK, BK, true>(a, grid, st, ktile); else launch<128, 128, AK, BK, false>(a, grid, st, ktile); }
-    else             { if (splitk) launch<64, 64, AK, BK, true>(a, grid, st, ktile);   else launch<64, 64, AK, BK, false>(a, grid, st, ktile); }
+void launch_tile(int t, bool splitk, const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
+    if (splitk) launch_tile2<AK, BK, true>(t, a, grid, st, ktile);
+    else launch_tile2<AK, BK, false>(t, a, grid, st, ktile);
 }
 
 int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
@@ -660,16 +694,10 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.H = d.H; a.W = d.W; a.Cin = d.Cin;
     a.kt_total = 0; a.kt_per_split = 0; a.slab_stride = 0;
 
-    // tile choice: 128x128 when that still gives >= 1.5 blocks per CU, else 64x64
-    auto ntiles = [&](int t) {
-        long long nm = (d.M + t - 1) / t;
-        long long nn = wgrad ? 9LL * ((d.Cin + t - 1) / t) : (d.N + t - 1) / t;
-        return nm * nn;
-    };
-    int tile = d.tile;
-    if (tile != 128 && tile != 64) tile = (ntiles(128) * batch * splitk >= 384 && d.N > 64 && d.M > 64) ? 128 : 64;
-    const long long nm = (d.M + tile - 1) / tile;
-    const long long nn = wgrad ? 9LL * ((d.Cin + tile - 1) / tile) : (d.N + tile - 1) / tile;
+    const int tile = choose_tile(d.M, wgrad ? d.Cin : d.N, wgrad, (long long)batch * splitk, d.tile);
+    const int tbm = TILES[tile].bm, tbn = TILES[tile].bn;
+    const long long nm = (d.M + tbm - 1) / tbm;
+    const long long nn = wgrad ? 9LL * ((d.Cin + tbn - 1) / tbn) : (d.N + tbn - 1) / tbn;
     VD_REQUIRE(nm <= 65535, "vd_gemm: too many row tiles (%lld)", nm);
     const int ktile = ktile_for(a, tile, nm * nn * batch, splitk > 1);
     a.kt_total = conv ? 9 * ((d.Cin + ktile - 1) / ktile) : (d.K + ktile - 1) / ktile;
@@ -733,13 +761,14 @@ extern "C" int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, con
     return run_gemm(d, (hipStream_t)stream);
 }
 
-static int wgrad_split(int nimg, int H, int W, int Cin, int Cout) {
-    // All blocks of the split-K launch do equal work and 2 of them fit a CU (KT = 32 kernel, 64 KB LDS), so the launch
-    // runs in "rounds" of 512 resident blocks: pick the slab count that fills whole rounds as exactly as possible (a
-    // 756-block launch took two rounds for 1.48 rounds of work), keeping >= 512 pixels of K per slab.
+// Split-K plan of the conv weight gradient.  All blocks of the launch do equal work and `per_cu` of them fit a CU, so the
+// launch runs in "rounds" of 256*per_cu resident blocks: pick the slab count that fills whole rounds as exactly as
+// possible (a 756-block launch on 512 slots took two rounds for 1.48 rounds of work), keeping >= 512 pixels per slab.
+static void wgrad_plan(int nimg, int H, int W, int Cin, int Cout, int* tile_out, int* split_out) {
+    const int t = choose_tile(Cout, Cin, true, 64, 0);   // the slab count below fills the chip whatever the tile
     const long long kt = ((long long)nimg * H * W + 31) / 32;
-    const long long tiles = ((Cout + 127) / 128) * 9LL * ((Cin + 127) / 128);
-    const long long slots = 512;
+    const long long tiles = ((Cout + TILES[t].bm - 1) / TILES[t].bm) * 9LL * ((Cin + TILES[t].bn - 1) / TILES[t].bn);
+    const long long slots = 256LL * TILES[t].per_cu;
     int best = 1;
     double best_eff = 0.0;
     for (int s = 1; s <= 64; ++s) {
@@ -750,11 +779,13 @@ static int wgrad_split(int nimg, int H, int W, int Cin, int Cout) {
         eff *= 1.0 - 0.004 * s;                       // mild preference for fewer slabs (less reduce traffic)
         if (eff > best_eff) { best_eff = eff; best = s; }
     }
-    return best;
+    *tile_out = t; *split_out = best;
 }
 
 extern "C" size_t vd_conv3x3_wgrad_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
-    return (size_t)wgrad_split(nimg, H, W, Cin, Cout) * Cout * 9 * Cin * sizeof(float);
+    int t, S;
+    wgrad_plan(nimg, H, W, Cin, Cout, &t, &S);
+    return (size_t)S * Cout * 9 * Cin * sizeof(float);
 }
 
 extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
@@ -763,7 +794,9 @@ extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, 
     hipStream_t st = (hipStream_t)stream;
     VD_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "vd_conv3x3_wgrad: Cin/Cout must be multiples of 4 (%d,%d)", Cin, Cout);
     VD_REQUIRE(Cin_w <= Cin && Cout_w <= Cout, "vd_conv3x3_wgrad: real dims exceed padded dims");
-    const int S = wgrad_split(nimg, H, W, Cin, Cout);
+    int t, S;
+    wgrad_plan(nimg, H, W, Cin, Cout, &t, &S);
+    static const int codes[4] = {128, 12864, 64128, 64};
     VD_REQUIRE(ws && ws_bytes >= (size_t)S * Cout * 9 * Cin * 4, "vd_conv3x3_wgrad: workspace too small");
     vd_gemm_desc d = {};
     d.A = dy; d.B = xin; d.C = ws;
@@ -772,7 +805,7 @@ extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, 
     d.lda = lddy; d.ldb = ldx; d.ldc = 9LL * Cin;
     d.batch = 1; d.nh = 1; d.alpha = 1.f;
     d.H = H; d.W = W; d.Cin = Cin;
-    d.splitk = S; d.ws = ws; d.ws_bytes = (int64_t)ws_bytes; d.tile = 128;
+    d.splitk = S; d.ws = ws; d.ws_bytes = (int64_t)ws_bytes; d.tile = codes[t];
     const long long slab = (long long)Cout * 9 * Cin;
     int used = S;
     if (S > 1) {

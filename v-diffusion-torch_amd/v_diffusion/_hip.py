@@ -132,7 +132,8 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None and exc[0] is None:
             self.e1.record()
-            PROFILE.append((self.name.format(tile=lib().vd_gemm_last_tile()), self.flops, self.e0, self.e1))
+            t = lib().vd_gemm_last_tile()
+            PROFILE.append((self.name.format(tile=f"{t // 1000}, {t % 1000}"), self.flops, self.e0, self.e1))
 
 
 def workspace(nbytes, device, tag="default"):
@@ -160,13 +161,13 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     if splitk > 1:
         ws = workspace(splitk * M * N * 4, A.device, "splitk")
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    with _Timed("gemm_dma_kernel<{tile}, {tile}, " + f"{a_kind}, {b_kind}, " + ("true>" if splitk > 1 else "false>"),
+    with _Timed("gemm_dma_kernel<{tile}, " + f"{a_kind}, {b_kind}, " + ("true>" if splitk > 1 else "false>"),
                 2.0 * M * N * K * batch):
         _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False):
-    with _Timed("gemm_dma_kernel<{tile}, {tile}, 2, 0, false>", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _Timed("gemm_dma_kernel<{tile}, 2, 0, false>", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3(ptr(x), ldx, ptr(wpack), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
                                 int(accumulate), stream()), "vd_conv3x3")
 
@@ -174,7 +175,7 @@ def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False):
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
-    with _Timed("gemm_dma_kernel<{tile}, {tile}, 1, 2, true> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _Timed("gemm_dma_kernel<{tile}, 1, 2, true> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), Cin_w, Cout_w,
                                       int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
 
