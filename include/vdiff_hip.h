@@ -55,6 +55,8 @@ typedef struct vd_gemm_desc {
     int32_t splitk;             /* >1: K is split over `splitk` slabs in ws, then reduced into C    */
     float*  ws; int64_t ws_bytes;
     int32_t tile;               /* 0 = auto; 128, 64, 12864 (128x64), 64128 (64x128) force the block tile */
+    float*  colsum;             /* optional, VD_COL A only: colsum[m] (+)= sum_k A[k][m] (bias gradient of a */
+    int32_t colsum_accumulate;  /*   weight-gradient GEMM, computed from the tiles already staged); batch = 1  */
 } vd_gemm_desc;
 
 /* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two
@@ -72,13 +74,14 @@ int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, const float* b
                const float* res, int64_t ldres, float* y, int64_t ldy,
                int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate, void* stream);
 
-/* weight gradient of the same convolution, summed over the whole batch (autograd of F.conv2d):
+/* weight (and bias) gradient of the same convolution, summed over the whole batch (autograd of F.conv2d):
  *   dw_oihw[co][ci][tap] (+)= sum_{b,y,x} dy[b,y,x,co] * xin[b,y+dy,x+dx,ci]      co < Cout_w, ci < Cin_w
+ *   dbias[co]            (+)= sum_{b,y,x} dy[b,y,x,co]                             (dbias may be NULL)
  * xin has Cin (multiple of 4, >= Cin_w) channels, dy has Cout (multiple of 4, >= Cout_w) channels. */
 size_t vd_conv3x3_wgrad_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t lddy,
                      int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                     float* dw_oihw, int32_t Cin_w, int32_t Cout_w, int32_t accumulate,
+                     float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w, int32_t accumulate,
                      float* ws, size_t ws_bytes, void* stream);
 
 /* OIHW (Cout_w, Cin_w, 3, 3) -> wf[Cout_w][9][Cin_p]  (forward)  and/or  wd[Cin_w][9][Cout_p] with the taps

@@ -77,6 +77,20 @@ def test_gemm_batched_heads_accumulate(H):
     close(S, ref64 + 1.0, None, floor=3e-6, name="batched QK^T")
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(64, 96, 4096, 8), (256, 36, 128, 1), (768, 256, 8192, 6), (12, 260, 1000, 3)])
+@pytest.mark.parametrize("tile", [0, 128, 64, 12864, 64128])
+def test_gemm_colsum_rides_on_wgrad(H, M, N, K, splitk, tile):
+    """bias gradient = column sums of the COL-kind A operand, produced by the weight-gradient GEMM itself"""
+    A, B = rnd(K, M, seed=8), rnd(K, N, seed=9)
+    Cd = torch.zeros(M, N, device=DEV)
+    cs = torch.ones(M, device=DEV)
+    H.gemm(A.to(DEV), B.to(DEV), Cd, M, N, K, a_kind=1, b_kind=1, lda=M, ldb=N, ldc=N, splitk=splitk, tile=tile, colsum=cs,
+           colsum_accumulate=True)
+    torch.cuda.synchronize()
+    close(Cd, A.double().T @ B.double(), A.T @ B, name="wgrad gemm")
+    close(cs, A.double().sum(0) + 1.0, A.sum(0) + 1.0, name="colsum")
+
+
 @pytest.mark.parametrize("kinds", [(1, 1), (0, 0), (0, 1)])
 def test_gemm_splitk(H, kinds):
     a_kind, b_kind = kinds
@@ -171,9 +185,11 @@ def test_conv3x3_wgrad(H, case):
     w32 = torch.zeros(Cout_w, Cin_w, 3, 3, requires_grad=True)
     F.conv2d(x[:, :Cin_w], w32, padding=1).backward(dy[:, :Cout_w])
     dw = torch.ones(Cout_w, Cin_w, 3, 3, device=DEV)
-    H.conv3x3_wgrad(nhwc(x), Cin, nhwc(dy), Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin_w, Cout_w, accumulate=True)
+    db = torch.ones(Cout_w, device=DEV)
+    H.conv3x3_wgrad(nhwc(x), Cin, nhwc(dy), Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin_w, Cout_w, accumulate=True, dbias=db)
     torch.cuda.synchronize()
     close(dw, w64.grad + 1.0, w32.grad + 1.0, name="conv wgrad")
+    close(db, dy[:, :Cout_w].double().sum((0, 2, 3)) + 1.0, dy[:, :Cout_w].sum((0, 2, 3)) + 1.0, name="conv dbias")
 
 
 # ------------------------------------------------------------------------------------------------ GroupNorm family

@@ -33,6 +33,7 @@ struct GemmArgs {
     int H, W, Cin;
     int kt_total, kt_per_split;
     long long slab_stride;
+    float* colsum; int colsum_accumulate;     // COL-kind A only: colsum[m] (+)= sum_k A[k][m]  (bias gradients ride along)
 };
 
 __device__ __forceinline__ int row_swz(int row, int chunk) { return row * KT + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -221,6 +222,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // bias gradient riding on the weight-gradient GEMM: the A operand of a COL-kind launch is dY, whose column sums are
+    // d(bias).  The waves of n-tile 0 / wave column 0 already stream every A fragment through registers.
+    float csum[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) csum[a] = 0.f;
+    const bool do_cs = (AK == VD_COL) && p.colsum != nullptr && blockIdx.x == 0 && (wave & 1) == 0;
+
     auto compute = [&](int buf) {
         const float* as = As + buf * BM * KT;
         const float* bs = Bs + buf * BN * KT;
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if (AK == VD_COL) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
+                    if (do_cs) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
                 } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz(row, 2 * s + lh));
             }
 #pragma unroll
@@ -270,6 +279,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         }
     }
 
+    if (AK == VD_COL && do_cs) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const float v = csum[a] + __shfl_xor(csum[a], 32, 64);
+            const int m = m0 + wm + 32 * a + li;
+            if (lh == 0 && m < p.M) {
+                float* o = p.colsum + (SPLITK ? (long long)blockIdx.z * p.M : 0) + m;
+                *o = (!SPLITK && p.colsum_accumulate) ? *o + v : v;
+            }
+        }
+    }
     // ---- epilogue: D[row][col], col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
@@ -477,6 +497,13 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // bias gradient riding on the weight-gradient GEMM: the A operand of a COL-kind launch is dY, whose column sums are
+    // d(bias).  The waves of n-tile 0 / wave column 0 already stream every A fragment through registers.
+    float csum[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) csum[a] = 0.f;
+    const bool do_cs = (AK == VD_COL) && p.colsum != nullptr && blockIdx.x == 0 && (wave & 1) == 0;
+
     auto compute = [&](int buf) {
         const float* as = smem + buf * (BM * KT);
         const float* bs = smem + 2 * BM * KT + buf * (BN * KT);
@@ -489,6 +516,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                 if (AK == VD_COL) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
+                    if (do_cs) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
                 } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 2 * s + lh));
             }
 #pragma unroll
@@ -524,6 +552,17 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         }
     }
 
+    if (AK == VD_COL && do_cs) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const float v = csum[a] + __shfl_xor(csum[a], 32, 64);
+            const int m = m0 + wm + 32 * a + li;
+            if (lh == 0 && m < p.M) {
+                float* o = p.colsum + (SPLITK ? (long long)blockIdx.z * p.M : 0) + m;
+                *o = (!SPLITK && p.colsum_accumulate) ? *o + v : v;
+            }
+        }
+    }
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int ncol = wn + 32 * b + li;
@@ -551,8 +590,14 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
 
 // out (+)= sum over slabs; optional OIHW transposition for the conv weight gradient
 __global__ void reduce_slabs_kernel(const float* slabs, int S, long long slab_stride, int M, int N, float* out,
-                                    long long ldo, int accumulate, float alpha) {
+                                    long long ldo, int accumulate, float alpha, const float* cpart, float* colsum,
+                                    int colsum_accumulate) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (colsum && idx < M) {            // bias gradient partials of the same launch
+        float c = 0.f;
+        for (int z = 0; z < S; ++z) c += cpart[(long long)z * M + idx];
+        colsum[idx] = colsum_accumulate ? colsum[idx] + c : c;
+    }
     if (idx >= (long long)M * N) return;
     float s = 0.f;
     for (int z = 0; z < S; ++z) s += slabs[z * slab_stride + idx];
@@ -563,9 +608,14 @@ __global__ void reduce_slabs_kernel(const float* slabs, int S, long long slab_st
 }
 
 __global__ void reduce_slabs_oihw_kernel(const float* slabs, int S, long long slab_stride, int Cout, int Cin,
-                                         int Cout_w, int Cin_w, float* dw, int accumulate) {
+                                         int Cout_w, int Cin_w, float* dw, int accumulate, const float* cpart, float* dbias) {
     // slab element (co, tap*Cin + ci) -> dw[(co*Cin_w + ci)*9 + tap]
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dbias && idx < Cout_w) {
+        float c = 0.f;
+        for (int z = 0; z < S; ++z) c += cpart[(long long)z * Cout + idx];
+        dbias[idx] = accumulate ? dbias[idx] + c : c;
+    }
     const long long total = (long long)Cout * 9 * Cin;
     if (idx >= total) return;
     const int co = idx / (9 * Cin), rem = idx % (9 * Cin);
@@ -693,6 +743,8 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.alpha = d.alpha; a.accumulate = d.accumulate;
     a.H = d.H; a.W = d.W; a.Cin = d.Cin;
     a.kt_total = 0; a.kt_per_split = 0; a.slab_stride = 0;
+    a.colsum = d.colsum; a.colsum_accumulate = d.colsum_accumulate;
+    VD_REQUIRE(!(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
 
     const int tile = choose_tile(d.M, wgrad ? d.Cin : d.N, wgrad, (long long)batch * splitk, d.tile);
     const int tbm = TILES[tile].bm, tbn = TILES[tile].bn;
@@ -709,8 +761,11 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
         const int used = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;
         g_last_slabs = used;
         a.slab_stride = (long long)d.M * d.N;
-        VD_REQUIRE(d.ws && d.ws_bytes >= (int64_t)(used * a.slab_stride * 4), "vd_gemm: split-K workspace too small");
+        VD_REQUIRE(d.ws && d.ws_bytes >= (int64_t)((used * a.slab_stride + (d.colsum ? (long long)used * d.M : 0)) * 4),
+                   "vd_gemm: split-K workspace too small");
         a.C = d.ws; a.ldc = d.N;
+        float* cpart = d.ws + used * a.slab_stride;          // per-slab bias-gradient partials live behind the slabs
+        if (d.colsum) a.colsum = cpart;
         dim3 grid(nn, nm, used);
         if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, true, a, grid, st, ktile);
         else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, true, a, grid, st, ktile);
@@ -721,7 +776,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
         if (!wgrad) {   // plain reduce here; the conv wgrad caller reduces with the OIHW transposition itself
             const long long tot = (long long)d.M * d.N;
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, d.ws, used, a.slab_stride,
-                               d.M, d.N, final_C, d.ldc, d.accumulate, d.alpha);
+                               d.M, d.N, final_C, d.ldc, d.accumulate, d.alpha, cpart, d.colsum, d.colsum_accumulate);
             VD_LAUNCH_CHECK("reduce_slabs_kernel");
         }
         return 0;
@@ -785,19 +840,19 @@ static void wgrad_plan(int nimg, int H, int W, int Cin, int Cout, int* tile_out,
 extern "C" size_t vd_conv3x3_wgrad_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     int t, S;
     wgrad_plan(nimg, H, W, Cin, Cout, &t, &S);
-    return (size_t)S * Cout * 9 * Cin * sizeof(float);
+    return (size_t)S * ((size_t)Cout * 9 * Cin + Cout) * sizeof(float);
 }
 
 extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
-                                int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, int32_t Cin_w, int32_t Cout_w,
-                                int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
+                                int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w,
+                                int32_t Cout_w, int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     VD_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "vd_conv3x3_wgrad: Cin/Cout must be multiples of 4 (%d,%d)", Cin, Cout);
     VD_REQUIRE(Cin_w <= Cin && Cout_w <= Cout, "vd_conv3x3_wgrad: real dims exceed padded dims");
     int t, S;
     wgrad_plan(nimg, H, W, Cin, Cout, &t, &S);
     static const int codes[4] = {128, 12864, 64128, 64};
-    VD_REQUIRE(ws && ws_bytes >= (size_t)S * Cout * 9 * Cin * 4, "vd_conv3x3_wgrad: workspace too small");
+    VD_REQUIRE(ws && ws_bytes >= (size_t)S * ((size_t)Cout * 9 * Cin + Cout) * 4, "vd_conv3x3_wgrad: workspace too small");
     vd_gemm_desc d = {};
     d.A = dy; d.B = xin; d.C = ws;
     d.M = Cout; d.N = 9 * Cin; d.K = nimg * H * W;
@@ -808,17 +863,22 @@ extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, 
     d.splitk = S; d.ws = ws; d.ws_bytes = (int64_t)ws_bytes; d.tile = codes[t];
     const long long slab = (long long)Cout * 9 * Cin;
     int used = S;
+    float* cpart = nullptr;
     if (S > 1) {
+        d.colsum = dbias;                      // run_gemm redirects it to the per-slab partial area behind the slabs
         int rc = run_gemm(d, st);
         if (rc) return rc;
         used = g_last_slabs;
+        cpart = ws + used * slab;
     } else {
         d.splitk = 1;
+        cpart = ws + slab;
+        d.colsum = dbias ? cpart : nullptr; d.colsum_accumulate = 0;
         int rc = run_gemm(d, st);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(reduce_slabs_oihw_kernel, dim3((slab + 255) / 256), dim3(256), 0, st, ws, used, slab, Cout, Cin,
-                       Cout_w, Cin_w, dw_oihw, accumulate);
+                       Cout_w, Cin_w, dw_oihw, accumulate, cpart, dbias);
     VD_LAUNCH_CHECK("reduce_slabs_oihw_kernel");
     return 0;
 }

@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                 ("sAb", _i64), ("sAh", _i64), ("sBb", _i64), ("sBh", _i64),
                 ("sCb", _i64), ("sCh", _i64), ("sRb", _i64), ("sRh", _i64),
                 ("alpha", _f32), ("accumulate", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32),
-                ("splitk", _i32), ("ws", _vp), ("ws_bytes", _i64), ("tile", _i32)]
+                ("splitk", _i32), ("ws", _vp), ("ws_bytes", _i64), ("tile", _i32),
+                ("colsum", _vp), ("colsum_accumulate", _i32)]
 
 
 _SIGNATURES = {
@@ -38,7 +39,7 @@ _SIGNATURES = {
     "vd_gemm_last_tile": (C.c_int, []),
     "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_pack_conv3x3": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "vd_gn_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "vd_gn_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
@@ -149,7 +150,8 @@ def workspace(nbytes, device, tag="default"):
 
 # ----------------------------------------------------------------------------------------------- wrappers
 def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None, R=None, ldr=0, batch=1, nh=1,
-         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), alpha=1.0, accumulate=False, splitk=1, tile=0):
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), alpha=1.0, accumulate=False, splitk=1, tile=0, colsum=None,
+         colsum_accumulate=False):
     d = GemmDesc()
     d.A, d.B, d.C, d.bias, d.R = ptr(A), ptr(B), ptr(Cm), ptr(bias), ptr(R)
     d.M, d.N, d.K, d.a_kind, d.b_kind = M, N, K, a_kind, b_kind
@@ -158,8 +160,9 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     (d.sAb, d.sAh), (d.sBb, d.sBh), (d.sCb, d.sCh), (d.sRb, d.sRh) = sA, sB, sC, sR
     d.alpha, d.accumulate = alpha, int(accumulate)
     d.splitk, d.tile = splitk, tile
+    d.colsum, d.colsum_accumulate = ptr(colsum), int(colsum_accumulate)
     if splitk > 1:
-        ws = workspace(splitk * M * N * 4, A.device, "splitk")
+        ws = workspace(splitk * (M * N + M) * 4, A.device, "splitk")
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     with _Timed("gemm_dma_kernel<{tile}, " + f"{a_kind}, {b_kind}, " + ("true>" if splitk > 1 else "false>"),
                 2.0 * M * N * K * batch):
@@ -172,11 +175,11 @@ def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=
                                 int(accumulate), stream()), "vd_conv3x3")
 
 
-def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False):
+def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
     with _Timed("gemm_dma_kernel<{tile}, 1, 2, true> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
-        _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), Cin_w, Cout_w,
+        _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w,
                                       int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
 
 

@@ -154,9 +154,8 @@ class UNetEngine:
         """dw[N,K] = dy^T x ; db[N] = colsum(dy) ; dx[M,K] (+)= dy @ w"""
         M, K = x.shape
         N = w.shape[0]
-        H.gemm(dy, x, dw, N, K, M, a_kind=H.COL, b_kind=H.COL, lda=dy.stride(0), ldb=x.stride(0), ldc=K, splitk=_splitk(N, K, M))
-        if db is not None:
-            H.colsum(dy, dy.stride(0), M, N, db)
+        H.gemm(dy, x, dw, N, K, M, a_kind=H.COL, b_kind=H.COL, lda=dy.stride(0), ldb=x.stride(0), ldc=K, splitk=_splitk(N, K, M),
+               colsum=db)                                          # db = column sums of dy, from the same staged tiles
         if dx is not None:
             H.gemm(dy, w, dx, M, K, N, a_kind=H.ROW, b_kind=H.COL, lda=dy.stride(0), ldb=w.stride(0), ldc=dx.stride(0),
                    accumulate=dx_accumulate)
@@ -255,8 +254,8 @@ class UNetEngine:
         _, Ho, Wo, Cout, lddy = _chk(dy)
         rs = blk.rs
         # conv2
-        H.conv3x3_wgrad(a2, Cout, dy, lddy, B, Ho, Wo, Cout, Cout, G[prefix + ".conv2.weight"], Cout, Cout)
-        H.colsum(dy, lddy, B * Ho * Wo, Cout, G[prefix + ".conv2.bias"])
+        H.conv3x3_wgrad(a2, Cout, dy, lddy, B, Ho, Wo, Cout, Cout, G[prefix + ".conv2.weight"], Cout, Cout,
+                        dbias=G[prefix + ".conv2.bias"])
         da2 = self._new(x, B, Ho, Wo, Cout)
         H.conv3x3(dy, lddy, self._pack_d(mod.conv2.weight), None, da2, Cout, B, Ho, Wo, Cout, Cout)
         # norm2 + FiLM + SiLU + dropout
@@ -267,8 +266,8 @@ class UNetEngine:
                        B, Ho, Wo, Cout, GROUPS)
         del da2
         # conv1
-        H.conv3x3_wgrad(a1, Cin, dh1, Cout, B, Ho, Wo, Cin, Cout, G[prefix + ".conv1.weight"], Cin, Cout)
-        H.colsum(dh1, Cout, B * Ho * Wo, Cout, G[prefix + ".conv1.bias"])
+        H.conv3x3_wgrad(a1, Cin, dh1, Cout, B, Ho, Wo, Cin, Cout, G[prefix + ".conv1.weight"], Cin, Cout,
+                        dbias=G[prefix + ".conv1.bias"])
         da1 = self._new(x, B, Ho, Wo, Cin)
         H.conv3x3(dh1, Cout, self._pack_d(mod.conv1.weight), None, da1, Cin, B, Ho, Wo, Cout, Cin)
         del dh1
@@ -278,8 +277,7 @@ class UNetEngine:
             P = B * Ho * Wo
             w = mod.skip.weight
             H.gemm(dy, xs, G[prefix + ".skip.weight"], Cout, Cin, P, a_kind=H.COL, b_kind=H.COL, lda=lddy, ldb=_ld(xs), ldc=Cin,
-                   splitk=_splitk(Cout, Cin, P))
-            H.colsum(dy, lddy, P, Cout, G[prefix + ".skip.bias"])
+                   splitk=_splitk(Cout, Cin, P), colsum=G[prefix + ".skip.bias"])
             dsk = self._new(x, B, Ho, Wo, Cin)
             H.gemm(dy, w, dsk, P, Cin, Cout, a_kind=H.ROW, b_kind=H.COL, lda=lddy, ldb=Cin, ldc=Cin)
         else:
@@ -334,8 +332,7 @@ class UNetEngine:
         M = B * L
         # proj_out
         H.gemm(dy, O, G[prefix + ".proj_out.weight"], C, hid, M, a_kind=H.COL, b_kind=H.COL, lda=lddy, ldb=hid, ldc=hid,
-               splitk=_splitk(C, hid, M))
-        H.colsum(dy, lddy, M, C, G[prefix + ".proj_out.bias"])
+               splitk=_splitk(C, hid, M), colsum=G[prefix + ".proj_out.bias"])
         dO = self._new(x, B, L, hid)
         H.gemm(dy, mod.proj_out.weight, dO, M, hid, C, a_kind=H.ROW, b_kind=H.COL, lda=lddy, ldb=hid, ldc=hid)
         dqkv = self._new(x, B, L, ld)
@@ -355,8 +352,7 @@ class UNetEngine:
         del dP, dO
         # proj_in
         H.gemm(dqkv, xn, G[prefix + ".proj_in.weight"], ld, C, M, a_kind=H.COL, b_kind=H.COL, lda=ld, ldb=C, ldc=C,
-               splitk=_splitk(ld, C, M))
-        H.colsum(dqkv, ld, M, ld, G[prefix + ".proj_in.bias"])
+               splitk=_splitk(ld, C, M), colsum=G[prefix + ".proj_in.bias"])
         dxn = self._new(x, B, Hh, Ww, C)
         H.gemm(dqkv, mod.proj_in.weight, dxn, M, C, ld, a_kind=H.ROW, b_kind=H.COL, lda=ld, ldb=C, ldc=C)
         # norm (no activation) + the residual branch
@@ -452,10 +448,7 @@ class UNetEngine:
         gn, conv = m.out_conv[0], m.out_conv[2]
         o = tape["out"]
         co = m.out_channels
-        H.conv3x3_wgrad(o["a"], C0, dout, cop, B, H0, W0, C0, cop, G["out_conv.2.weight"], C0, co)
-        bt = self._new(dout, cop)
-        H.colsum(dout, cop, B * H0 * W0, cop, bt)
-        G["out_conv.2.bias"].copy_(bt[:co])
+        H.conv3x3_wgrad(o["a"], C0, dout, cop, B, H0, W0, C0, cop, G["out_conv.2.weight"], C0, co, dbias=G["out_conv.2.bias"])
         da = self._new(dout, B, H0, W0, C0)
         H.conv3x3(dout, cop, self._pack_d(conv.weight, cop), None, da, C0, B, H0, W0, cop, C0)
         dh = self._new(dout, B, H0, W0, C0)
@@ -501,8 +494,8 @@ class UNetEngine:
         assert not dskip
         x4 = tape["in"]["x4"]
         cip = x4.shape[3]
-        H.conv3x3_wgrad(x4, cip, dy0, _ld(dy0), B, H0, W0, cip, m.hid_channels, G["in_conv.weight"], m.in_channels, m.hid_channels)
-        H.colsum(dy0, _ld(dy0), B * H0 * W0, m.hid_channels, G["in_conv.bias"])
+        H.conv3x3_wgrad(x4, cip, dy0, _ld(dy0), B, H0, W0, cip, m.hid_channels, G["in_conv.weight"], m.in_channels, m.hid_channels,
+                        dbias=G["in_conv.bias"])
         progress("in_conv.bias")
         dx = None
         if need_dx:
