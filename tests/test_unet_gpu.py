@@ -292,3 +292,47 @@ def test_hot_path_trainer_matches_torch_optimizer(vd):
     # the module still round-trips through state_dict in the reference layout
     sd = model.state_dict()
     assert list(sd.keys()) == list(ref.state_dict().keys())
+
+
+@pytest.mark.parametrize("B,Hh,Ww", [(1, 8, 16), (5, 16, 8), (2, 4, 4)])
+def test_ragged_batch_and_non_square_images(vd, B, Hh, Ww):
+    """edge cases the reference handles implicitly: batch of one, odd batch, non-square images, 2x2 bottleneck"""
+    from oracle import unet_ref, detrand
+    from oracle.cases import TINY
+    cfg = TINY["tinyA"]["cfg"]
+    model, sd = _build(vd, cfg, train=True)
+    x = detrand.normal("xr", (B, 3, Hh, Ww), 7)
+    t = detrand.uniform("tr", (B,), 7, dtype=torch.float64)
+    y = detrand.randint("yr", (B,), 0, 11, 7).float()
+    gout = detrand.normal("gr", (B, 3, Hh, Ww), 7)
+    out = model(x.to(DEV), t.to(DEV), y.to(DEV))
+    (out * gout.to(DEV)).sum().backward()
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oo = unet_ref.unet_forward(sdo, cfg, x, t, y)
+    (oo * gout).sum().backward()
+    assert (out.detach().cpu() - oo.detach()).abs().max().item() <= 2e-5
+    gmax = max(v.grad.norm().item() for v in sdo.values())
+    for k, p in model.named_parameters():
+        err = (p.grad.cpu() - sdo[k].grad).norm().item()
+        assert err <= 1e-4 * sdo[k].grad.norm().item() + 1e-6 * gmax, k
+
+
+def test_ddp_wrapper_single_process(vd):
+    """DistributedDataParallel(UNet) -- the reference's own multi-GPU path (train.py:148) -- runs on the single autograd node"""
+    import torch.distributed as dist
+    from oracle.cases import TINY, make_inputs
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        case = TINY["tinyA"]
+        model, _ = _build(vd, case["cfg"], train=True)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        x, t, y = (v.to(DEV) for v in make_inputs(case["cfg"], 4, case["R"], case["label"]))
+        gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine"), 8, "v", "fixed_large", "snr_trunc", "mse", p_uncond=0.0)
+        gd.train_loss(ddp, x.clamp(-1, 1), t, y).mean().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    finally:
+        dist.destroy_process_group()

@@ -351,6 +351,12 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     constexpr int A_LPR = BM / 4, B_LPR = BN / 4;        // lanes per k-row of a row-contiguous tile
     constexpr int A_RPP = 64 / A_LPR, B_RPP = 64 / B_LPR;// k-rows per piece
     constexpr int RLPR = KT / 4, RRPP = 64 / RLPR;       // k-contiguous tile: lanes per row, rows per piece
+    // Row-contiguous ([k][rows]) operands with two 32-row MFMA blocks per wave: lane i reads rows 2i, 2i+1 with ONE
+    // ds_read_b64 and block a takes element a, i.e. MFMA block a owns the interleaved rows {2i + a} instead of
+    // {32a + i}.  Halves the LDS instructions of the weight-gradient kernels; only the output row/column map changes.
+    constexpr bool A2 = (AK == VD_COL) && (MT == 2);
+    constexpr bool B2 = (BK != VD_ROW) && (NT == 2);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -510,22 +516,42 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
 #pragma unroll
         for (int s = 0; s < KT / 8; ++s) {
             f32x4 fa[MT], fb[NT];
+            if (A2) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int row = wm + 32 * a + li;
-                if (AK == VD_COL) {
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(as + (8 * s + 4 * lh + j) * BM + wm + 2 * li);
+                    fa[0][j] = v[0]; fa[MT - 1][j] = v[1];
+                }
+                if (do_cs) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
-                    if (do_cs) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
-                } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 2 * s + lh));
+                    for (int a = 0; a < MT; ++a) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const int row = wm + 32 * a + li;
+                    if (AK == VD_COL) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
+                        if (do_cs) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
+                    } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 2 * s + lh));
+                }
             }
+            if (B2) {
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int row = wn + 32 * b + li;
-                if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz_t<KT>(row, 2 * s + lh));
-                else {
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(bs + (8 * s + 4 * lh + j) * BN + wn + 2 * li);
+                    fb[0][j] = v[0]; fb[NT - 1][j] = v[1];
+                }
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fb[b][j] = bs[(8 * s + 4 * lh + j) * BN + row];
+                for (int b = 0; b < NT; ++b) {
+                    const int row = wn + 32 * b + li;
+                    if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz_t<KT>(row, 2 * s + lh));
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fb[b][j] = bs[(8 * s + 4 * lh + j) * BN + row];
+                    }
                 }
             }
 #pragma unroll
@@ -556,7 +582,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const float v = csum[a] + __shfl_xor(csum[a], 32, 64);
-            const int m = m0 + wm + 32 * a + li;
+            const int m = m0 + wm + (A2 ? 2 * li + a : 32 * a + li);
             if (lh == 0 && m < p.M) {
                 float* o = p.colsum + (SPLITK ? (long long)blockIdx.z * p.M : 0) + m;
                 *o = (!SPLITK && p.colsum_accumulate) ? *o + v : v;
@@ -565,7 +591,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     }
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
-        const int ncol = wn + 32 * b + li;
+        const int ncol = wn + (B2 ? 2 * li + b : 32 * b + li);
         const int n = n0 + ncol;
         const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
         if (!nok) continue;
@@ -574,7 +600,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int rt = (r & 3) + 8 * (r >> 2) + 4 * lh;              // row inside the 32x32 MFMA block
+                const int m = m0 + wm + (A2 ? 2 * rt + a : 32 * a + rt);
                 if (m >= p.M) continue;
                 float v = acc[a][b][r];
                 if (!SPLITK) {
