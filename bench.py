@@ -191,8 +191,17 @@ def main():
         total_t = sum(v[1] for v in agg.values())
         dom = max(agg, key=lambda k: agg[k][1])
         fl, tt, n = agg[dom]
+        traffic = None
+        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/parse_rocprof.py)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            key = dom.split(" (+")[0]
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / tt / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": "HBM+fabric bytes per launch, PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r01_traffic.json",
                     "launches_per_step": n // 2, "avg_launch_ms": round(tt / n * 1e3, 4),
                     "flops_per_launch": round(fl / n / 1e9, 3), "flops_unit": "GFLOP (2*M*N*K of the implicit GEMM)",
                     "share_of_matmul_time": round(tt / total_t, 3),

@@ -721,7 +721,7 @@ inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk) {
 
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
-    g_last_tile = BM * 1000 + BN;
+    g_last_tile = ((use_dma(a) ? ((BM == 128 && BN == 128 && ktile == 16) ? 16 : 32) : 0) * 1000 + BM) * 1000 + BN;
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
     else if (BM == 128 && BN == 128 && ktile == 16)
         hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, ((BM == 128 && BN == 128) ? 16 : 32)>), grid, dim3(256), 0, st, a);

@@ -115,7 +115,7 @@ _ws_cache = {}
 
 # When set to a list, the matmul-shaped wrappers append (kernel_name, flops, start_event, end_event) per launch
 # (bench.py uses it for the live roofline figure; events sit on the stream the kernels are launched on).  Names are the
-# rocprofv3 kernel names: gemm_dma_kernel<BM, BN, a_kind, b_kind, splitk> with kinds 0 = ROW, 1 = COL, 2 = IM2COL.
+# rocprofv3 kernel names: gemm_dma_kernel<BM, BN, a_kind, b_kind, splitk, KT> with kinds 0 = ROW, 1 = COL, 2 = IM2COL.
 PROFILE = None
 _KIND = {0: "ROW", 1: "COL", 2: "IM2COL"}
 
@@ -134,7 +134,11 @@ class _Timed:
         if PROFILE is not None and exc[0] is None:
             self.e1.record()
             t = lib().vd_gemm_last_tile()
-            PROFILE.append((self.name.format(tile=f"{t // 1000}, {t % 1000}"), self.flops, self.e0, self.e1))
+            kt, bm, bn = t // 1000000, (t // 1000) % 1000, t % 1000
+            name = self.name.format(tile=f"{bm}, {bn}", kt=kt)
+            if kt == 0:
+                name = name.replace("gemm_dma_kernel", "gemm_kernel").replace(", 0>", ">")
+            PROFILE.append((name, self.flops, self.e0, self.e1))
 
 
 def workspace(nbytes, device, tag="default"):
@@ -164,13 +168,13 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     if splitk > 1:
         ws = workspace(splitk * (M * N + M) * 4, A.device, "splitk")
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
-    with _Timed("gemm_dma_kernel<{tile}, " + f"{a_kind}, {b_kind}, " + ("true>" if splitk > 1 else "false>"),
+    with _Timed("gemm_dma_kernel<{tile}, " + f"{a_kind}, {b_kind}, " + ("true, {kt}>" if splitk > 1 else "false, {kt}>"),
                 2.0 * M * N * K * batch):
         _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False):
-    with _Timed("gemm_dma_kernel<{tile}, 2, 0, false>", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _Timed("gemm_dma_kernel<{tile}, 2, 0, false, {kt}>", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3(ptr(x), ldx, ptr(wpack), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
                                 int(accumulate), stream()), "vd_conv3x3")
 
@@ -178,7 +182,7 @@ def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
-    with _Timed("gemm_dma_kernel<{tile}, 1, 2, true> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _Timed("gemm_dma_kernel<{tile}, 1, 2, true, {kt}> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w,
                                       int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
 
