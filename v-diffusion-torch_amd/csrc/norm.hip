@@ -24,20 +24,23 @@ struct ReduceArgs {
     float* part;                          // [nimg][chunks][2][C]
 };
 
-// gradient wrt the pre-activation z of one float4 of the forward input
-__device__ __forceinline__ f32x4 dz_of(const ReduceArgs& p, const float* dy_img, int y, int x, int c4, f32x4 xv, f32x4 sc,
+// gradient wrt the pre-activation z of one float4 of the forward input (pixel `pix` of an H x W image)
+__device__ __forceinline__ f32x4 dz_of(const ReduceArgs& p, const float* dy_img, int pix, int c4, f32x4 xv, f32x4 sc,
                                        f32x4 of, unsigned long long vec_index) {
     f32x4 g;
     if (p.resample == VD_RS_NONE) {
-        g = *reinterpret_cast<const f32x4*>(dy_img + ((long long)y * p.W + x) * p.lddy + c4);
-    } else if (p.resample == VD_RS_DOWN) {
-        const int Wo = p.W >> 1;
-        g = *reinterpret_cast<const f32x4*>(dy_img + ((long long)(y >> 1) * Wo + (x >> 1)) * p.lddy + c4) * 0.25f;
+        g = *reinterpret_cast<const f32x4*>(dy_img + (long long)pix * p.lddy + c4);
     } else {
-        const int Wo = p.W << 1;
-        const float* b0 = dy_img + ((long long)(2 * y) * Wo + 2 * x) * p.lddy + c4;
-        g = *reinterpret_cast<const f32x4*>(b0) + *reinterpret_cast<const f32x4*>(b0 + p.lddy) +
-            *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy) + *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy + p.lddy);
+        const int y = pix / p.W, x = pix - y * p.W;
+        if (p.resample == VD_RS_DOWN) {
+            const int Wo = p.W >> 1;
+            g = *reinterpret_cast<const f32x4*>(dy_img + ((long long)(y >> 1) * Wo + (x >> 1)) * p.lddy + c4) * 0.25f;
+        } else {
+            const int Wo = p.W << 1;
+            const float* b0 = dy_img + ((long long)(2 * y) * Wo + 2 * x) * p.lddy + c4;
+            g = *reinterpret_cast<const f32x4*>(b0) + *reinterpret_cast<const f32x4*>(b0 + p.lddy) +
+                *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy) + *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy + p.lddy);
+        }
     }
     if (p.p_drop > 0.f) g *= vd_dropout_scale4(p.seed, vec_index, p.p_drop);
     if (p.act) {
@@ -76,11 +79,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ReduceArgs p, in
             const long long HWo = p.resample == VD_RS_DOWN ? p.HW / 4 : (p.resample == VD_RS_UP ? p.HW * 4 : p.HW);
             const float* dimg = p.dy + (long long)b * HWo * p.lddy;
             for (int i = r; i < np; i += rows) {
-                const long long pix = pix0 + i;
-                const int y = (int)(pix / p.W), x = (int)(pix % p.W);
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(ximg + pix * p.ldx + c4);
+                const int pix = (int)pix0 + i;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
                 const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * (p.C >> 2) + (c4 >> 2);
-                const f32x4 dz = dz_of(p, dimg, y, x, c4, xv, sc, of, vi);
+                const f32x4 dz = dz_of(p, dimg, pix, c4, xv, sc, of, vi);
                 a0 += dz;
                 a1 += dz * (xv * nr + nm);
             }
@@ -149,9 +151,8 @@ struct ApplyArgs {
     int resample; float* y; long long ldy; int nimg, H, W, C;
 };
 
-__device__ __forceinline__ f32x4 fwd_one(const ApplyArgs& p, const float* ximg, long long pix, int c4, f32x4 sc, f32x4 of,
-                                         int b) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(ximg + pix * p.ldx + c4);
+__device__ __forceinline__ f32x4 fwd_one(const ApplyArgs& p, const float* ximg, int pix, int c4, f32x4 sc, f32x4 of, int b) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
     if (p.has_norm) v = v * sc + of;
     if (p.act) {
 #pragma unroll
@@ -164,34 +165,40 @@ __device__ __forceinline__ f32x4 fwd_one(const ApplyArgs& p, const float* ximg, 
     return v;
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const ApplyArgs p) {
-    const int vecs = p.C >> 2;
+constexpr int APIX = 64;     // output pixels per workgroup of the apply kernels
+
+// grid (pixel chunks, images, channel splits): a thread keeps ONE float4 of channels for all its pixels, so the
+// coefficient table is read once per thread and the loop has no 64-bit index arithmetic
+__global__ __launch_bounds__(256) void gn_apply_kernel(const ApplyArgs p, int Cb) {
+    const int b = blockIdx.y, c0 = blockIdx.z * Cb;
+    const int vecs = min(Cb, p.C - c0) >> 2, rows = 256 / vecs;
+    const int r = threadIdx.x / vecs, c4 = c0 + 4 * (threadIdx.x % vecs);
+    if (r >= rows) return;
     const int Ho = p.resample == VD_RS_DOWN ? p.H >> 1 : (p.resample == VD_RS_UP ? p.H << 1 : p.H);
     const int Wo = p.resample == VD_RS_DOWN ? p.W >> 1 : (p.resample == VD_RS_UP ? p.W << 1 : p.W);
-    const long long per_img = (long long)Ho * Wo * vecs, total = per_img * p.nimg;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / per_img);
-        const long long rem = idx % per_img;
-        const long long po = rem / vecs;
-        const int c4 = (int)(rem % vecs) * 4;
-        const int yo = (int)(po / Wo), xo = (int)(po % Wo);
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f};
-        if (p.has_norm) {
-            const float* cf = p.coef + (long long)b * 4 * p.C;
-            sc = *reinterpret_cast<const f32x4*>(cf + c4);
-            of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
-        }
-        const float* ximg = p.x + (long long)b * p.H * p.W * p.ldx;
+    const int p0 = blockIdx.x * APIX, np = min(APIX, Ho * Wo - p0);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f};
+    if (p.has_norm) {
+        const float* cf = p.coef + (long long)b * 4 * p.C;
+        sc = *reinterpret_cast<const f32x4*>(cf + c4);
+        of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
+    }
+    const float* ximg = p.x + (long long)b * p.H * p.W * p.ldx;
+    float* yimg = p.y + (long long)b * Ho * Wo * p.ldy;
+    for (int i = r; i < np; i += rows) {
+        const int po = p0 + i;
         f32x4 out;
         if (p.resample == VD_RS_NONE) out = fwd_one(p, ximg, po, c4, sc, of, b);
-        else if (p.resample == VD_RS_UP) out = fwd_one(p, ximg, (long long)(yo >> 1) * p.W + (xo >> 1), c4, sc, of, b);
         else {
-            const long long q = (long long)(2 * yo) * p.W + 2 * xo;
-            out = (fwd_one(p, ximg, q, c4, sc, of, b) + fwd_one(p, ximg, q + 1, c4, sc, of, b) +
-                   fwd_one(p, ximg, q + p.W, c4, sc, of, b) + fwd_one(p, ximg, q + p.W + 1, c4, sc, of, b)) * 0.25f;
+            const int yo = po / Wo, xo = po - yo * Wo;
+            if (p.resample == VD_RS_UP) out = fwd_one(p, ximg, (yo >> 1) * p.W + (xo >> 1), c4, sc, of, b);
+            else {
+                const int q = (2 * yo) * p.W + 2 * xo;
+                out = (fwd_one(p, ximg, q, c4, sc, of, b) + fwd_one(p, ximg, q + 1, c4, sc, of, b) +
+                       fwd_one(p, ximg, q + p.W, c4, sc, of, b) + fwd_one(p, ximg, q + p.W + 1, c4, sc, of, b)) * 0.25f;
+            }
         }
-        *reinterpret_cast<f32x4*>(p.y + ((long long)b * Ho * Wo + po) * p.ldy + c4) = out;
+        *reinterpret_cast<f32x4*>(yimg + (long long)po * p.ldy + c4) = out;
     }
 }
 
@@ -265,40 +272,42 @@ struct BwdApplyArgs {
     ReduceArgs r; const float* q; const float* add; long long ldadd; float* dx; long long lddx; int accumulate_dx;
 };
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const BwdApplyArgs a) {
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const BwdApplyArgs a, int Cb) {
     const ReduceArgs& p = a.r;
-    const int vecs = p.C >> 2;
-    const long long per_img = p.HW * vecs, total = per_img * p.nimg;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / per_img);
-        const long long rem = idx % per_img;
-        const long long pix = rem / vecs;
-        const int c4 = (int)(rem % vecs) * 4;
-        const int y = (int)(pix / p.W), x = (int)(pix % p.W);
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f}, nr = sc, nm = of;
-        if (p.has_norm) {
-            const float* cf = p.coef + (long long)b * 4 * p.C;
-            sc = *reinterpret_cast<const f32x4*>(cf + c4);
-            of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
-            nr = *reinterpret_cast<const f32x4*>(cf + 2 * p.C + c4);
-            nm = *reinterpret_cast<const f32x4*>(cf + 3 * p.C + c4);
-        }
-        const long long HWo = p.resample == VD_RS_DOWN ? p.HW / 4 : (p.resample == VD_RS_UP ? p.HW * 4 : p.HW);
-        const float* dimg = p.dy + (long long)b * HWo * p.lddy;
+    const int b = blockIdx.y, c0 = blockIdx.z * Cb;
+    const int vecs = min(Cb, p.C - c0) >> 2, rows = 256 / vecs;
+    const int r = threadIdx.x / vecs, c4 = c0 + 4 * (threadIdx.x % vecs);
+    if (r >= rows) return;
+    const int HW = (int)p.HW;
+    const int p0 = blockIdx.x * APIX, np = min(APIX, HW - p0);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f}, nr = sc, nm = of;
+    f32x4 q0 = sc, q1 = of, q2 = of;
+    if (p.has_norm) {
+        const float* cf = p.coef + (long long)b * 4 * p.C;
+        sc = *reinterpret_cast<const f32x4*>(cf + c4);
+        of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
+        nr = *reinterpret_cast<const f32x4*>(cf + 2 * p.C + c4);
+        nm = *reinterpret_cast<const f32x4*>(cf + 3 * p.C + c4);
+        const float* qq = a.q + (long long)b * 3 * p.C;
+        q0 = *reinterpret_cast<const f32x4*>(qq + c4);
+        q1 = *reinterpret_cast<const f32x4*>(qq + p.C + c4);
+        q2 = *reinterpret_cast<const f32x4*>(qq + 2 * p.C + c4);
+    }
+    const long long HWo = p.resample == VD_RS_DOWN ? p.HW / 4 : (p.resample == VD_RS_UP ? p.HW * 4 : p.HW);
+    const float* dimg = p.dy + (long long)b * HWo * p.lddy;
+    const float* ximg = p.has_norm ? p.x + (long long)b * p.HW * p.ldx : nullptr;
+    const float* aimg = a.add ? a.add + (long long)b * p.HW * a.ldadd : nullptr;
+    float* oimg = a.dx + (long long)b * p.HW * a.lddx;
+    const int vtot = p.C >> 2;
+    for (int i = r; i < np; i += rows) {
+        const int pix = p0 + i;
         f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-        if (p.has_norm) xv = *reinterpret_cast<const f32x4*>(p.x + ((long long)b * p.HW + pix) * p.ldx + c4);
-        const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vecs + (c4 >> 2);
-        f32x4 d = dz_of(p, dimg, y, x, c4, xv, sc, of, vi);
-        if (p.has_norm) {
-            const float* qq = a.q + (long long)b * 3 * p.C;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qq + c4);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qq + p.C + c4);
-            const f32x4 q2 = *reinterpret_cast<const f32x4*>(qq + 2 * p.C + c4);
-            d = q0 * d - q1 - (xv * nr + nm) * q2;
-        }
-        if (a.add) d += *reinterpret_cast<const f32x4*>(a.add + ((long long)b * p.HW + pix) * a.ldadd + c4);
-        float* o = a.dx + ((long long)b * p.HW + pix) * a.lddx + c4;
+        if (p.has_norm) xv = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
+        const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
+        f32x4 d = dz_of(p, dimg, pix, c4, xv, sc, of, vi);
+        if (p.has_norm) d = q0 * d - q1 - (xv * nr + nm) * q2;
+        if (aimg) d += *reinterpret_cast<const f32x4*>(aimg + (long long)pix * a.ldadd + c4);
+        float* o = oimg + (long long)pix * a.lddx + c4;
         if (a.accumulate_dx) d += *reinterpret_cast<const f32x4*>(o);
         *reinterpret_cast<f32x4*>(o) = d;
     }
@@ -375,7 +384,9 @@ extern "C" int vd_gn_apply(const float* x, int64_t ldx, const float* stats, cons
     ApplyArgs p = {x, ldx, coef, has_norm, act, p_drop, seed, resample, y, ldy, nimg, H, W, C};
     const long long Ho = resample == VD_RS_DOWN ? H / 2 : (resample == VD_RS_UP ? H * 2 : H);
     const long long Wo = resample == VD_RS_DOWN ? W / 2 : (resample == VD_RS_UP ? W * 2 : W);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(Ho * Wo * (C / 4) * nimg)), dim3(256), 0, st, p);
+    const int Cba = pick_cb(C);
+    VD_REQUIRE(C % Cba == 0 && Cba % 4 == 0 && Cba <= 1024 && nimg <= 65535, "vd_gn_apply: cannot split C=%d / nimg=%d", C, nimg);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((Ho * Wo + APIX - 1) / APIX), nimg, C / Cba), dim3(256), 0, st, p, Cba);
     VD_LAUNCH_CHECK("gn_apply_kernel");
     return 0;
 }
@@ -416,7 +427,9 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
         VD_LAUNCH_CHECK("sum_over_images_kernel");
         a.q = q;
     }
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(HW * (C / 4) * nimg)), dim3(256), 0, st, a);
+    const int Cba = pick_cb(C);
+    VD_REQUIRE(C % Cba == 0 && Cba % 4 == 0 && Cba <= 1024 && nimg <= 65535, "vd_gn_apply_bwd: cannot split C=%d / nimg=%d", C, nimg);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((HW + APIX - 1) / APIX), nimg, C / Cba), dim3(256), 0, st, a, Cba);
     VD_LAUNCH_CHECK("gn_bwd_apply_kernel");
     return 0;
 }
