@@ -165,8 +165,10 @@ int vd_loss_bwd(const float* x0, const float* eps, const float* xt, const float*
  * out has n*(1+cfg) images, cond/uncond interleaved when cfg (diffusion.py:369-372).
  * k: 8 HOST floats {a0, b0x, b0e, c1, c2, noise_scale, w_guide, 0}:  x0_hat = clip(a0*xt + b0x*out (+ b0e*out_eps)),
  * mean = last_step ? x0_hat : c1*xt + c2*x0_hat, guided = mean_c + w (mean_c - mean_u), xn = guided + noise_scale*noise.
- * xdup (optional): the new state duplicated to 2n interleaved images = the next CFG UNet input. */
-int vd_sample_step(const float* xt, const float* out, const float* noise, const float* k,
+ * xdup (optional): the new state duplicated to 2n interleaved images = the next CFG UNet input.
+ * Exactly one of k (host) / k_dev (device, same 8 floats) is given: the device form keeps the launch replayable from a
+ * captured HIP graph with per-step coefficients.  xn may alias xt (element-wise in-place update). */
+int vd_sample_step(const float* xt, const float* out, const float* noise, const float* k, const float* k_dev,
                    int32_t model_out_type, int32_t cfg, int32_t last_step, int32_t clip,
                    float* xn, float* xdup, int32_t n, int32_t C, int32_t HW, void* stream);
 

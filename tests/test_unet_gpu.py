@@ -336,3 +336,26 @@ def test_ddp_wrapper_single_process(vd):
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     finally:
         dist.destroy_process_group()
+
+
+def test_graph_sampler_equals_eager(vd):
+    """the HIP-graph replayed reverse chain gives bit-identical samples to the eager chain (same kernels, same order)"""
+    from oracle.cases import TINY
+    case = TINY["tinyA"]
+    model, _ = _build(vd, case["cfg"], train=False)
+    B, R, T = 3, case["R"], 6
+    y = torch.tensor([1.0, 7.0, 10.0])
+    for kw in (dict(use_ddim=True, w=1.0, vt="fixed_large"), dict(use_ddim=False, w=0.5, vt="fixed_medium"), dict(use_ddim=False, w=0.0, vt="fixed_large")):
+        gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine"), T, "v", kw["vt"], "snr_trunc", "mse", intp_frac=0.3, w_guide=kw["w"])
+        a = gd.p_sample(model, (B, 3, R, R), label=y, device=DEV, seed=5, use_ddim=kw["use_ddim"], use_graph=False)
+        b = gd.p_sample(model, (B, 3, R, R), label=y, device=DEV, seed=5, use_ddim=kw["use_ddim"], use_graph=True)
+        c = gd.p_sample(model, (B, 3, R, R), label=y, device=DEV, seed=5, use_ddim=kw["use_ddim"], use_graph=True)   # cached graph
+        assert torch.equal(a, b) and torch.equal(a, c), (a - b).abs().max()
+        assert len(gd._graphs) == 1
+    # weights changed in place -> the cached graph sees them (packing runs inside the graph)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+    a = gd.p_sample(model, (B, 3, R, R), label=y, device=DEV, seed=5, use_graph=False)
+    b = gd.p_sample(model, (B, 3, R, R), label=y, device=DEV, seed=5, use_graph=True)
+    assert torch.equal(a, b)

@@ -121,14 +121,15 @@ __global__ void loss_bwd_kernel(const LossArgs p, const float* aux, const float*
 }
 
 struct StepArgs {
-    const float* xt; const float* out; const float* noise; float k[8];
+    const float* xt; const float* out; const float* noise; float k[8]; const float* kdev;
     int type, cfg, last, clip; float* xn; float* xdup; int n, C; long long HW;
 };
 
 // one reverse step for a batch sharing the step index; x0_hat = a0*xt + b0x*o (+ b0e*o_eps), mean = c1*xt + c2*x0_hat
 __global__ void sample_step_kernel(const StepArgs p) {
     const long long N = (long long)p.C * p.HW, total = (long long)p.n * N;
-    const float a0 = p.k[0], b0x = p.k[1], b0e = p.k[2], c1 = p.k[3], c2 = p.k[4], nscale = p.k[5], w = p.k[6];
+    const float* kp = p.kdev ? p.kdev : p.k;       // device-resident coefficients keep the launch HIP-graph replayable
+    const float a0 = kp[0], b0x = kp[1], b0e = kp[2], c1 = kp[3], c2 = kp[4], nscale = kp[5], w = kp[6];
     const int mul = 1 + p.cfg, Co = p.type == OUT_BOTH ? 2 * p.C : p.C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -142,7 +143,7 @@ __global__ void sample_step_kernel(const StepArgs p) {
             mean[u] = p.last ? x0h : c1 * xt + c2 * x0h;
         }
         float v = p.cfg ? mean[0] + w * (mean[0] - mean[1]) : mean[0];
-        if (nscale != 0.f) v += nscale * p.noise[idx];
+        if (p.noise) v += nscale * p.noise[idx];
         p.xn[idx] = v;
         if (p.xdup) { p.xdup[(2 * b) * N + i] = v; p.xdup[(2 * b + 1) * N + i] = v; }
     }
@@ -186,14 +187,14 @@ extern "C" int vd_loss_bwd(const float* x0, const float* eps, const float* xt, c
     return 0;
 }
 
-extern "C" int vd_sample_step(const float* xt, const float* out, const float* noise, const float* k, int32_t type, int32_t cfg,
-                              int32_t last_step, int32_t clip, float* xn, float* xdup, int32_t n, int32_t C, int32_t HW,
-                              void* stream) {
-    VD_REQUIRE(k != nullptr, "vd_sample_step: null coefficient block (host pointer expected)");
-    VD_REQUIRE(noise != nullptr || k[5] == 0.f, "vd_sample_step: noise required when the noise scale is non-zero");
+extern "C" int vd_sample_step(const float* xt, const float* out, const float* noise, const float* k, const float* k_dev,
+                              int32_t type, int32_t cfg, int32_t last_step, int32_t clip, float* xn, float* xdup, int32_t n,
+                              int32_t C, int32_t HW, void* stream) {
+    VD_REQUIRE((k != nullptr) != (k_dev != nullptr), "vd_sample_step: pass the coefficients either as host k or as device k_dev");
+    VD_REQUIRE(noise != nullptr || k_dev != nullptr || k[5] == 0.f, "vd_sample_step: noise required when the noise scale is non-zero");
     StepArgs p = {};
-    p.xt = xt; p.out = out; p.noise = noise;
-    for (int i = 0; i < 8; ++i) p.k[i] = k[i];
+    p.xt = xt; p.out = out; p.noise = noise; p.kdev = k_dev;
+    for (int i = 0; i < 8; ++i) p.k[i] = k ? k[i] : 0.f;
     p.type = type; p.cfg = cfg; p.last = last_step; p.clip = clip; p.xn = xn; p.xdup = xdup; p.n = n; p.C = C; p.HW = HW;
     hipLaunchKernelGGL(sample_step_kernel, dim3(grid_for((long long)n * C * HW)), dim3(256), 0, (hipStream_t)stream, p);
     VD_LAUNCH_CHECK("sample_step_kernel");

@@ -62,7 +62,7 @@ _SIGNATURES = {
     "vd_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
-    "vd_sample_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(_f32), _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_sample_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(_f32), _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumsq_ws_bytes": (_sz, [_i64]),
     "vd_sumsq": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "vd_adamw_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
@@ -280,10 +280,11 @@ def loss_bwd(x0, eps, xt, out, logsnr, aux, gloss, mot, rw, dout, n, Cc, HW):
                              n, Cc, HW, stream()), "vd_loss_bwd")
 
 
-def sample_step(xt, out, noise, k8, mot, cfg, last, clip, xn, xdup, n, Cc, HW):
-    arr = (_f32 * 8)(*[float(v) for v in k8])
-    _check(lib().vd_sample_step(ptr(xt), ptr(out), ptr(noise), arr, mot, int(cfg), int(last), int(clip), ptr(xn), ptr(xdup),
-                                n, Cc, HW, stream()), "vd_sample_step")
+def sample_step(xt, out, noise, k8, mot, cfg, last, clip, xn, xdup, n, Cc, HW, k_dev=None):
+    """k8: 8 host floats, or None with k_dev = device tensor of 8 floats (graph-replayable form)"""
+    arr = None if k8 is None else (_f32 * 8)(*[float(v) for v in k8])
+    _check(lib().vd_sample_step(ptr(xt), ptr(out), ptr(noise), arr, ptr(k_dev), mot, int(cfg), int(last), int(clip), ptr(xn),
+                                ptr(xdup), n, Cc, HW, stream()), "vd_sample_step")
 
 
 def sumsq(g, out1):
