@@ -34,6 +34,7 @@ struct GemmArgs {
     int kt_total, kt_per_split;
     long long slab_stride;
     float* colsum; int colsum_accumulate;     // COL-kind A only: colsum[m] (+)= sum_k A[k][m]  (bias gradients ride along)
+    int probe;                                // timing experiments only (VD_GEMM_PROBE): bit0/bit1 drop the A/B tile loads
 };
 
 __device__ __forceinline__ int row_swz(int row, int chunk) { return row * KT + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -330,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB = 0x80000000u;      // >= num_records of every descriptor below
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)OOB, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
 }
 
 // k-contiguous LDS image: [row][KT] floats, 16-byte chunk index XOR-swizzled so that a ds_read_b128 of 32 consecutive
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             if (AK == VD_IM2COL) { aoff = (long long)((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.lda + c0; kwidth = p.Cin - c0; }
             else if (AK == VD_ROW) { aoff = (long long)kt * KT; kwidth = p.K - kt * KT; }
             else { aoff = (long long)kt * KT * p.lda; kwidth = p.K - kt * KT; }
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Ablk + aoff);
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Ablk + aoff, p.probe & 1 ? 0 : (int)OOB);   // probe: timing-only build knob
 #pragma unroll
             for (int j = 0; j < AIT; ++j) {
                 unsigned vo = voA[j];
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                 if (AK == VD_IM2COL) { boff = (long long)tapA * p.Cin + ccA * KT; kwidth = p.Cin - ccA * KT; }
                 else { boff = (long long)kt * KT; kwidth = p.K - kt * KT; }
             } else { boff = (long long)kt * KT * p.ldb + tapoffB; kwidth = p.K - kt * KT; }
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Bblk + boff);
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Bblk + boff, p.probe & 2 ? 0 : (int)OOB);
             const int dy = tapN / 3 - 1, dx = tapN % 3 - 1;
 #pragma unroll
             for (int j = 0; j < BIT; ++j) {
@@ -569,6 +570,13 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int buf = 0;
+        if (p.probe & 4) {           // timing probe only (wrong results): no barrier in the main loop
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
+                compute(buf);
+                buf ^= 1;
+            }
+        } else
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
             compute(buf);
@@ -693,6 +701,8 @@ const TileCfg TILES[4] = {{128, 128, 1.00, 2}, {128, 64, 0.92, 3}, {64, 128, 0.9
 // cheapest tile = least (padded MFMA work / per-tile efficiency), with a penalty when the launch cannot give every CU
 // at least two workgroups
 int choose_tile(long long M, long long Ncols, bool wgrad, long long zcount, int forced) {
+    static const char* env = getenv("VD_GEMM_TILE");        // experiments only
+    if (env && forced == 0) forced = atoi(env);
     if (forced == 128) return 0;
     if (forced == 12864) return 1;
     if (forced == 64128) return 2;
@@ -771,6 +781,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.H = d.H; a.W = d.W; a.Cin = d.Cin;
     a.kt_total = 0; a.kt_per_split = 0; a.slab_stride = 0;
     a.colsum = d.colsum; a.colsum_accumulate = d.colsum_accumulate;
+    { static const char* e = getenv("VD_GEMM_PROBE"); a.probe = e ? atoi(e) : 0; }
     VD_REQUIRE(!(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
 
     const int tile = choose_tile(d.M, wgrad ? d.Cin : d.N, wgrad, (long long)batch * splitk, d.tile);
