@@ -334,8 +334,59 @@ def test_ddp_wrapper_single_process(vd):
         gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine"), 8, "v", "fixed_large", "snr_trunc", "mse", p_uncond=0.0)
         gd.train_loss(ddp, x.clamp(-1, 1), t, y).mean().backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        # the build's own bucketed reducer over RCCL (one rank: all-reduce is an identity, the plumbing is real):
+        # async launches from the autograd thread while backward runs, waits at the end, same result as without it
+        import copy
+        from v_diffusion.trainer import HotPathTrainer
+        m1, _ = _build(vd, case["cfg"], train=True)
+        m2 = copy.deepcopy(m1)
+        t1 = HotPathTrainer(m1, gd, lr=1e-3, warmup=0, use_ema=False)
+        t2 = HotPathTrainer(m2, gd, lr=1e-3, warmup=0, use_ema=False)
+        t2.reducer.active = True
+        t2.reducer.bounds = [(a, min(a + 65536, t2.flat.numel)) for a in range(0, t2.flat.numel, 65536)]
+        for _ in range(2):
+            l1, l2 = t1.step(x.clamp(-1, 1), y.clone()), t2.step(x.clamp(-1, 1), y.clone())
+        assert float(l1) == float(l2) and torch.equal(t1.flat.p, t2.flat.p)
+        assert len(t2.reducer.bounds) > 8
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_properties_bs32(vd):
+    """BASELINE-size CIFAR UNet, batch 32 (no oracle at this size: size-independent properties instead):
+    run-to-run determinism, data-parallel additivity of gradients, linearity of the loss gradient in the upstream seed."""
+    from oracle.cases import CIFAR_COND
+    cfg = dict(CIFAR_COND, drop_rate=0.0)
+    torch.manual_seed(0)
+    model = vd.UNet(**cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.ndim >= 2 and float(p.abs().max()) == 0:
+                p.normal_(0, p[0].numel() ** -0.5)
+    model.to(DEV).train()
+    g = torch.Generator(DEV).manual_seed(3)
+    B = 32
+    x = torch.rand((B, 3, 32, 32), device=DEV, generator=g) * 2 - 1
+    t = torch.rand((B,), dtype=torch.float64, device=DEV, generator=g)
+    y = torch.randint(1, 11, (B,), device=DEV, generator=g).float()
+    gout = torch.randn((B, 3, 32, 32), device=DEV, generator=g)
+
+    def grads(sl, scale=1.0):
+        model.zero_grad(set_to_none=True)
+        out = model(x[sl], t[sl], y[sl])
+        (out * gout[sl] * scale).sum().backward()
+        return out.detach(), [p.grad.clone() for p in model.parameters()]
+    o1, g1 = grads(slice(0, B))
+    o2, g2 = grads(slice(0, B))
+    assert torch.equal(o1, o2) and all(torch.equal(a, b) for a, b in zip(g1, g2)), "not bitwise reproducible"
+    _, ga = grads(slice(0, B // 2))
+    _, gb = grads(slice(B // 2, B))
+    gmax = max(a.norm().item() for a in g1)
+    for f, a, b in zip(g1, ga, gb):
+        assert (f - (a + b)).norm().item() <= 5e-5 * f.norm().item() + 1e-6 * gmax
+    _, g3 = grads(slice(0, B), scale=2.0)
+    for f, a in zip(g1, g3):
+        assert (2 * f - a).norm().item() <= 1e-6 * max(f.norm().item(), 1e-9) + 1e-7 * gmax
 
 
 def test_graph_sampler_equals_eager(vd):

@@ -91,7 +91,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             ax[it] = rem % p.W;
         }
     }
-    const int cchA = (AK == VD_IM2COL) ? (p.Cin + KT - 1) / KT : 1;
     // K-tile cursor of the im2col A operand: (tap, channel chunk), advanced once per load_tiles call (tiles are
     // visited in order), so the main loop has no integer division
     // (taps are the FAST index: the 9 shifted reads of one 32-channel slab are adjacent in time and hit L1/L2)
@@ -394,7 +393,6 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     unsigned mkA[AIT];                 // IM2COL A: bit t set <=> tap t of this row is inside the image
     int kcA[AIT], kcB[BIT];            // k-contiguous tiles: first k (floats) of the 16-byte chunk this lane fetches
     int by[BIT], bx[BIT];              // IM2COL B: image coordinates of this lane's pixel row
-    const int cchA = (AK == VD_IM2COL) ? (p.Cin + KT - 1) / KT : 1;
     // K tiles of the im2col A operand are ordered (channel slab, tap) with the TAP as the fast index: the nine shifted
     // reads of one 32-channel slab of the block's pixel window are adjacent in time, so eight of them hit L1/L2 instead of
     // going back to the fabric (rocprof FETCH_SIZE of the 256->256 @32x32 conv: see profiles/)

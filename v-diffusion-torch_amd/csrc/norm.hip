@@ -336,12 +336,6 @@ inline int pick_cb(int C) {           // channels handled by one reduction block
     return C / split;
 }
 
-inline int grid_for(long long total) {
-    long long g = (total + 255) / 256;
-    if (g > 256LL * 16) g = 256LL * 16;
-    return (int)(g < 1 ? 1 : g);
-}
-
 }  // namespace
 
 extern "C" size_t vd_gn_ws_bytes(int32_t nimg, int32_t HW, int32_t C) {

@@ -92,7 +92,6 @@ class UNetEngine:
                 add(f"upsamples.level_{i}.{nrb + 1}", "up", chs[i], chs[i], H.RS_UP, model.apply_attn[i], False, i, mods[nrb + 1])
         self.plan = plan
         # ---- static skip-stack analysis: which concat buffer does every pushed tensor land in?
-        stack = [("in_conv", hid)]                       # (producer, channels); hs ids are positions in `pushes`
         pushes = [["in_conv", hid, None, None]]          # [producer, Cs, consumer block index, Ch]
         sid = [0]
         for bi, b in enumerate(plan):

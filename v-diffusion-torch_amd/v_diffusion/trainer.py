@@ -98,8 +98,9 @@ class FlatState:
 class GradReducer:
     """Bucketed mean all-reduce of the flat gradient buffer, overlapped with the tail of backward."""
 
-    def __init__(self, flat: FlatState, world_size, bucket_bytes=BUCKET_BYTES, group=None):
+    def __init__(self, flat: FlatState, world_size, bucket_bytes=BUCKET_BYTES, group=None, force=False):
         self.flat, self.world, self.group = flat, world_size, group
+        self.active = world_size > 1 or force        # force: run the collectives even on one rank (tests)
         n, per = flat.numel, max(bucket_bytes // 4, 1)
         self.bounds = [(a, min(a + per, n)) for a in range(0, n, per)]
         # first flat offset AFTER each parameter, in completion order -> "ready prefix" length
@@ -116,7 +117,7 @@ class GradReducer:
 
     def ready(self, name):
         """Called by the backward pass when ``name`` (and everything before it in completion order) is final."""
-        if self.world == 1:
+        if not self.active:
             return
         upto = self.flat.numel if name is None else self.end_of[name]
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][1] <= upto:
@@ -124,7 +125,7 @@ class GradReducer:
             self.next_bucket += 1
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         while self.next_bucket < len(self.bounds):
             self._launch(*self.bounds[self.next_bucket])
