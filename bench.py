@@ -126,11 +126,13 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # (== local_rank on a real node; lets a 1-GPU box host a gloo dry run)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)   # "nccl" == RCCL on ROCm
+        backend = os.environ.get("VD_BENCH_BACKEND", "nccl")                                  # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
 
     import v_diffusion
     from v_diffusion import _hip
@@ -180,9 +182,10 @@ def main():
     roofline = None
     if rank == 0:
         _hip.PROFILE = []
-        for _ in range(2):
-            one_step()
-        torch.cuda.synchronize()
+    for _ in range(2):                  # every rank takes part (the steps contain collectives); only rank 0 records
+        one_step()
+    barrier()
+    if rank == 0:
         rec, _hip.PROFILE = _hip.PROFILE, None
         agg = {}
         for name, flops, e0, e1 in rec:
@@ -247,6 +250,7 @@ def main():
                            "global_batch": world * B, "per_gpu_batch": B, "resolution": RES, "parallelism": f"dp{world}",
                            "final_loss": round(final_loss, 5)},
                 "frac_of_fp32_mfma_peak_whole_step": round(3 * FWD_GFLOP_PER_IMG * B / (ms_per_step * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                 "roofline": roofline, "cpu_baseline": cpu, "sampling": sampling}
         print(json.dumps(line), flush=True)
     if world > 1:

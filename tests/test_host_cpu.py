@@ -128,6 +128,29 @@ def test_step_coefficients_match_reference_tables(golden_dir):
         np.testing.assert_allclose(k[0], np.sqrt(1 / (1 + np.exp(-np.float64(lt)))), rtol=1e-6)
 
 
+def test_per_sample_posterior_api_matches_oracle():
+    """p_mean_var / q_posterior_mean_var(_ddim): the reference's tensor-valued API (device-agnostic tensor expressions)"""
+    import v_diffusion
+    from oracle import diffusion_ref as dref, detrand
+    B = 4
+    xt, out = detrand.normal("pm_x", (B, 3, 8, 8), 1), detrand.normal("pm_o", (B, 6, 8, 8), 2)
+    sched = v_diffusion.get_logsnr_schedule("cosine")
+    s = torch.tensor([0.0, 0.1, 0.5, 0.9], dtype=torch.float64)
+    t = s + 0.1
+    ls, lt = sched(s).float().reshape(-1, 1, 1, 1), sched(t).float().reshape(-1, 1, 1, 1)
+    for mot in ("v", "x0", "eps", "both"):
+        o = out if mot == "both" else out[:, :3]
+        for ddim in (True, False):
+            gd = v_diffusion.GaussianDiffusion(sched, 8, mot, "fixed_medium", "snr_trunc", "mse", intp_frac=0.3)
+            mean, lv, pred = gd.p_mean_var(o, xt, ls, lt, clip_denoised=True, return_pred=True, use_ddim=ddim)
+            px0 = dref.predictions(mot, xt, o, lt)[0].clamp(-1, 1)
+            c1, c2, rv = dref.ddim_coefs(ls, lt) if ddim else dref.ddpm_coefs(ls, lt, "fixed_medium", 0.3)
+            torch.testing.assert_close(pred, px0, rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(mean, c1 * xt + c2 * px0, rtol=1e-6, atol=1e-6)
+            if not ddim:
+                torch.testing.assert_close(lv, rv, rtol=1e-6, atol=1e-6)
+
+
 def test_cpu_tensors_fail_loudly():
     import v_diffusion
     from oracle.cases import TINY, make_inputs

@@ -174,6 +174,43 @@ class GaussianDiffusion:
             return l.reshape(-1, 1, 1, 1)
         return tuple(map(one, ts))
 
+    # ------------------------------------------------------------------------------------------ per-sample posterior API
+    # (reference :297-356).  These keep the reference's tensor-valued log-SNR arguments (one value per sample) and are
+    # NOT what the samplers run -- p_sample / p_sample_step use the fused vd_sample_step kernel with host-computed
+    # coefficients.  They are small compositions of device tensor ops kept for callers of the reference API.
+    def q_posterior_mean_var(self, x_0, x_t, logsnr_s, logsnr_t, model_var_type=None, intp_frac=None):
+        c1, c2, logvar = logsnr_to_posterior(logsnr_s, logsnr_t, var_type=model_var_type or self.model_var_type,
+                                             intp_frac=self.intp_frac if intp_frac is None else intp_frac)
+        return c1 * x_t + c2 * x_0, logvar
+
+    def q_posterior_mean_var_ddim(self, x_0, x_t, logsnr_s, logsnr_t):
+        c1, c2, logvar = logsnr_to_posterior_ddim(logsnr_s, logsnr_t, eta=0.)
+        return c1 * x_t + c2 * x_0, logvar
+
+    def p_mean_var(self, model_out, x_t, logsnr_s, logsnr_t, clip_denoised, return_pred, use_ddim=False):
+        if self.model_var_type == "learned":
+            raise NotImplementedError("model_var_type='learned' is not supported (the reference asserts the same in train_loss)")
+        l = logsnr_t
+        s1, s0 = torch.sigmoid(l), torch.sigmoid(-l)
+        if self.model_out_type == "x0":
+            pred = model_out
+        elif self.model_out_type == "eps":
+            pred = x_t * s1.rsqrt() - model_out * torch.exp(-0.5 * l)
+        elif self.model_out_type == "v":
+            pred = x_t * s1.sqrt() - model_out * s0.sqrt()
+        elif self.model_out_type == "both":
+            x0p, epsp = model_out.chunk(2, dim=1)
+            pred = x0p * s0 + (x_t * s1.rsqrt() - epsp * torch.exp(-0.5 * l)) * s1
+        else:
+            raise NotImplementedError(self.model_out_type)
+        if clip_denoised:
+            pred = pred.clamp(-1., 1.)
+        if use_ddim:
+            mean, logvar = self.q_posterior_mean_var_ddim(pred, x_t, logsnr_s, logsnr_t)
+        else:
+            mean, logvar = self.q_posterior_mean_var(pred, x_t, logsnr_s, logsnr_t)
+        return (mean, logvar, pred) if return_pred else (mean, logvar)
+
     # ------------------------------------------------------------------------------------------ training
     def train_loss(self, denoise_fn, x_0, t, y, noise=None):
         """Per-sample loss (B,) -- reference :492-545, mse branch.  ``y`` is mutated in place by the label drop
