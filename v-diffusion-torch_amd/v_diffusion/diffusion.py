@@ -120,6 +120,14 @@ def _pred_coefs(model_out_type, lt32):
     raise NotImplementedError(model_out_type)
 
 
+def _device_ctx(device):
+    """make ``device`` the current HIP device for the duration of a sampler call (kernels use its current stream)"""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("GaussianDiffusion sampling: device must be an MI355X ('cuda'); there is no CPU path")
+    return torch.cuda.device(device)
+
+
 def _need_cuda(x, what):
     if not x.is_cuda:
         raise RuntimeError(f"GaussianDiffusion.{what}: tensors must live on an MI355X (no CPU path; see oracle/ for the CPU restatement)")
@@ -135,7 +143,8 @@ class _MSELoss(torch.autograd.Function):
         out = out.contiguous()
         loss = torch.empty((B,), dtype=torch.float32, device=x0.device)
         aux = torch.empty((B, 2), dtype=torch.float32, device=x0.device)
-        _hip.loss_fwd(x0, eps, xt, out, logsnr32, mot, rw, loss, aux, B, C, HW)
+        with torch.cuda.device(x0.device):
+            _hip.loss_fwd(x0, eps, xt, out, logsnr32, mot, rw, loss, aux, B, C, HW)
         ctx.save_for_backward(out, x0, eps, xt, logsnr32, aux)
         ctx.cfg = (mot, rw, B, C, HW)
         return loss
@@ -145,7 +154,8 @@ class _MSELoss(torch.autograd.Function):
         out, x0, eps, xt, logsnr32, aux = ctx.saved_tensors
         mot, rw, B, C, HW = ctx.cfg
         dout = torch.empty_like(out)
-        _hip.loss_bwd(x0, eps, xt, out, logsnr32, aux, gloss.to(torch.float32).contiguous(), mot, rw, dout, B, C, HW)
+        with torch.cuda.device(x0.device):
+            _hip.loss_bwd(x0, eps, xt, out, logsnr32, aux, gloss.to(torch.float32).contiguous(), mot, rw, dout, B, C, HW)
         return dout, None, None, None, None, None, None
 
 
@@ -228,7 +238,8 @@ class GaussianDiffusion:
         HW = x_0[0, 0].numel()
         logsnr32 = self.logsnr_fn(t).to(torch.float32).reshape(-1).contiguous()
         x_t = torch.empty_like(x_0)
-        _hip.q_sample(x_0, noise, logsnr32, x_t, B, C, HW)
+        with torch.cuda.device(x_0.device):
+            _hip.q_sample(x_0, noise, logsnr32, x_t, B, C, HW)
         model_out = denoise_fn(x_t, t, y)
         if self.p_uncond and y is not None:
             keep = (torch.rand((y.shape[0],)) > self.p_uncond).to(device=y.device, dtype=y.dtype)
@@ -399,15 +410,17 @@ class GaussianDiffusion:
     @torch.inference_mode()
     def p_sample(self, denoise_fn, shape, noise=None, label=None, device="cuda", seed=None, use_ddim=False, use_graph=None):
         """Full reverse chain (reference :394-414); returns a CPU tensor like the reference.  ``use_graph`` (extension):
-        None = replay a captured HIP graph when the UNet batch is small enough to be launch-bound, True/False forces it."""
-        x, _ = self._sample_loop(denoise_fn, tuple(shape), noise, label, device, seed, use_ddim, use_graph=use_graph)
+        True replays one captured HIP graph per reverse step (see _sample_loop_graph); default eager."""
+        with _device_ctx(device):
+            x, _ = self._sample_loop(denoise_fn, tuple(shape), noise, label, device, seed, use_ddim, use_graph=use_graph)
         return x.cpu()
 
     @torch.inference_mode()
     def p_sample_progressive(self, denoise_fn, shape, noise=None, label=None, device="cuda", seed=None, use_ddim=False,
                              pred_freq=50):
         """reference :416-441: also returns the x0 predictions every ``pred_freq`` steps (earliest step first)."""
-        x, preds = self._sample_loop(denoise_fn, tuple(shape), noise, label, device, seed, use_ddim, pred_freq)
+        with _device_ctx(device):
+            x, preds = self._sample_loop(denoise_fn, tuple(shape), noise, label, device, seed, use_ddim, pred_freq)
         L = self.sample_timesteps // pred_freq
         out = torch.zeros((L, shape[0]) + tuple(shape[1:]), dtype=torch.float32)
         for i, p in enumerate(preds):                          # preds were collected from the last index down

@@ -53,9 +53,10 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, t, y, *params):
         eng = model.engine()
-        out, tape = eng.forward(x, t, y, model.training, save=True)
-        ctx.model, ctx.tape, ctx.need_dx = model, tape, x.requires_grad
-        return model._to_nchw(out)
+        with torch.cuda.device(x.device):            # kernels go to the current stream of the tensor's device
+            out, tape = eng.forward(x, t, y, model.training, save=True)
+            ctx.model, ctx.tape, ctx.need_dx = model, tape, x.requires_grad
+            return model._to_nchw(out)
 
     @staticmethod
     def backward(ctx, dout):
@@ -66,11 +67,12 @@ class _UNetFn(torch.autograd.Function):
         eng = model.engine()
         B, co, Hh, Ww = dout.shape
         cop = (co + 3) // 4 * 4
-        d4 = torch.empty((B, Hh, Ww, cop), dtype=torch.float32, device=dout.device)
-        _hip.nchw_to_nhwc(dout.to(torch.float32).contiguous(), d4, B, co, Hh, Ww, cop)
         flat = model._flat_grad_views is not None
         G = model._grad_targets()
-        dx = eng.backward(tape, d4, G, need_dx=ctx.need_dx, progress=getattr(model, "_grads_ready_hook", None))
+        with torch.cuda.device(dout.device):
+            d4 = torch.empty((B, Hh, Ww, cop), dtype=torch.float32, device=dout.device)
+            _hip.nchw_to_nhwc(dout.to(torch.float32).contiguous(), d4, B, co, Hh, Ww, cop)
+            dx = eng.backward(tape, d4, G, need_dx=ctx.need_dx, progress=getattr(model, "_grads_ready_hook", None))
         if flat:
             # the kernels already wrote into the caller's flat gradient buffer (trainer.FlatState): autograd gets nothing
             # to accumulate, which avoids a 243 MB clone per step
@@ -174,5 +176,6 @@ class UNet(nn.Module):
         params = list(self.parameters())
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             return _UNetFn.apply(self, x, t, y, *params)
-        out, _ = self.engine().forward(x, t, y, self.training, save=False)
-        return self._to_nchw(out)
+        with torch.cuda.device(x.device):
+            out, _ = self.engine().forward(x, t, y, self.training, save=False)
+            return self._to_nchw(out)
