@@ -329,6 +329,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 // voffset + scalar soffset, so the loop has no 64-bit VALU address math and no branches.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB = 0x80000000u;      // >= num_records of every descriptor below
+#ifndef VD_SCHED_INTERLEAVE
+#define VD_SCHED_INTERLEAVE 1
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
@@ -509,57 +512,87 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     for (int a = 0; a < MT; ++a) csum[a] = 0.f;
     const bool do_cs = (AK == VD_COL) && p.colsum != nullptr && blockIdx.x == 0 && (wave & 1) == 0;
 
+    // fragment loads of sub-step s (8 k values): MT + NT LDS reads per wave
+    auto load_frags = [&](const float* as, const float* bs, int s, f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
+        if (A2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(as + (8 * s + 4 * lh + j) * BM + wm + 2 * li);
+                fa[0][j] = v[0]; fa[MT - 1][j] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = wm + 32 * a + li;
+                if (AK == VD_COL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
+                } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 2 * s + lh));
+            }
+        }
+        if (B2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(bs + (8 * s + 4 * lh + j) * BN + wn + 2 * li);
+                fb[0][j] = v[0]; fb[NT - 1][j] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int row = wn + 32 * b + li;
+                if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz_t<KT>(row, 2 * s + lh));
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[b][j] = bs[(8 * s + 4 * lh + j) * BN + row];
+                }
+            }
+        }
+    };
+    auto mfma_group = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
+        if (AK == VD_COL && do_cs) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+    };
+
+    // software pipeline over the KT/8 sub-steps: the fragments of sub-step s+1 are requested BEFORE the MFMAs of
+    // sub-step s, and sched_group_barrier spreads those LDS reads between the MFMAs so no wave sits on an lgkmcnt wait
+    // at a sub-step boundary
     auto compute = [&](int buf) {
         const float* as = smem + buf * (BM * KT);
         const float* bs = smem + 2 * BM * KT + buf * (BN * KT);
+        constexpr int S = KT / 8;
+        f32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        load_frags(as, bs, 0, fa0, fb0);
 #pragma unroll
-        for (int s = 0; s < KT / 8; ++s) {
-            f32x4 fa[MT], fb[NT];
-            if (A2) {
+        for (int s = 0; s < S; s += 2) {
+            if (s + 1 < S) load_frags(as, bs, s + 1, fa1, fb1);
+            mfma_group(fa0, fb0);
+            if (VD_SCHED_INTERLEAVE && AK != VD_COL && BK == VD_ROW) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(as + (8 * s + 4 * lh + j) * BM + wm + 2 * li);
-                    fa[0][j] = v[0]; fa[MT - 1][j] = v[1];
-                }
-                if (do_cs) {
-#pragma unroll
-                    for (int a = 0; a < MT; ++a) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
-                }
-            } else {
-#pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    const int row = wm + 32 * a + li;
-                    if (AK == VD_COL) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) fa[a][j] = as[(8 * s + 4 * lh + j) * BM + row];
-                        if (do_cs) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
-                    } else fa[a] = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 2 * s + lh));
+                for (int q = 0; q < MT + NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       // one LDS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (MT + NT), 0);   // a slice of the MFMAs
                 }
             }
-            if (B2) {
+            if (s + 1 < S) {
+                if (s + 2 < S) load_frags(as, bs, s + 2, fa0, fb0);
+                mfma_group(fa1, fb1);
+                if (VD_SCHED_INTERLEAVE && AK != VD_COL && BK == VD_ROW) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(bs + (8 * s + 4 * lh + j) * BN + wn + 2 * li);
-                    fb[0][j] = v[0]; fb[NT - 1][j] = v[1];
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    const int row = wn + 32 * b + li;
-                    if (BK == VD_ROW) fb[b] = *reinterpret_cast<const f32x4*>(bs + row_swz_t<KT>(row, 2 * s + lh));
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) fb[b][j] = bs[(8 * s + 4 * lh + j) * BN + row];
+                    for (int q = 0; q < MT + NT; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (MT + NT), 0);
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
     };
 
