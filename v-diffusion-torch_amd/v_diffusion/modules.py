@@ -5,8 +5,6 @@ On the hot path these modules do not compute: ``UNet.forward`` hands their param
 (reference checkpoints load unchanged, optimizer state is indexed by parameter order).
 """
 import math
-from collections.abc import Iterable
-from itertools import repeat
 
 import torch
 import torch.nn as nn
@@ -15,71 +13,73 @@ DEFAULT_DTYPE = torch.float32
 
 
 def lecun_normal_(tensor, scale: float = 1.):
-    """N(0,1) truncated at +-2, times sqrt(scale / fan_in); scale == 0 gives zeros (reference modules.py:25-35)."""
-    assert tensor.ndim >= 2
-    fan_in = tensor.shape[1] * (math.prod(tensor.shape[2:]) if tensor.ndim > 2 else 1)
-    nn.init.trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.)
+    """In place: N(0,1) truncated at +-2 sigma, times sqrt(scale / fan_in), no variance correction; scale == 0 gives
+    exact zeros (reference modules.py:25-35 -- the zero-initialised conv2 / proj_out / out_conv tensors rely on it)."""
+    if tensor.ndim < 2:
+        raise ValueError("lecun_normal_ needs a tensor with a fan-in dimension")
+    fan_in = tensor[0].numel()
     with torch.no_grad():
-        tensor.mul_(math.sqrt(scale / fan_in))
+        nn.init.trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.).mul_(math.sqrt(scale / fan_in))
     return tensor
 
 
 DEFAULT_INITIALIZER = lecun_normal_
 
 
-def pair(x):
-    return tuple(x) if isinstance(x, Iterable) else tuple(repeat(x, 2))
+def pair(v):
+    """int -> (int, int); sequences pass through as tuples"""
+    try:
+        return tuple(v)
+    except TypeError:
+        return (v, v)
 
 
-class Linear(nn.Module):
+class _WeightBias(nn.Module):
+    """``weight`` (+ optional ``bias``) holder shared by Linear and Conv2d: lecun-normal weight, zero bias."""
+
+    def _make(self, weight_shape, with_bias, init_scale):
+        self.init_scale = init_scale
+        self.weight = nn.Parameter(torch.empty(weight_shape, dtype=DEFAULT_DTYPE))
+        self.bias = nn.Parameter(torch.empty(weight_shape[:1], dtype=DEFAULT_DTYPE)) if with_bias else None
+        self._init()
+
+    def _init(self):
+        DEFAULT_INITIALIZER(self.weight, scale=self.init_scale)
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+
+
+class Linear(_WeightBias):
     """weight (out, in), bias (out) -- reference modules.py:55-84"""
 
     def __init__(self, in_features, out_features, bias=True, init_scale=1.):
         super().__init__()
-        self.in_features, self.out_features, self.init_scale = in_features, out_features, init_scale
-        self.weight = nn.Parameter(torch.empty((out_features, in_features), dtype=DEFAULT_DTYPE))
-        if bias:
-            self.bias = nn.Parameter(torch.empty((out_features,), dtype=DEFAULT_DTYPE))
-        else:
-            self.register_parameter("bias", None)
-        self.reset_parameters()
+        self.in_features, self.out_features = in_features, out_features
+        self._make((out_features, in_features), bias, init_scale)
 
-    def reset_parameters(self):
-        DEFAULT_INITIALIZER(self.weight, scale=self.init_scale)
-        if self.bias is not None:
-            nn.init.zeros_(self.bias)
+    reset_parameters = _WeightBias._init
 
     def extra_repr(self):
-        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
+        return f"{self.in_features} -> {self.out_features}, bias={self.bias is not None}"
 
 
-class Conv2d(nn.Module):
-    """weight OIHW, bias (O) -- reference modules.py:87-144.  Only the two shapes the UNet uses are executable on
-    the HIP path: 3x3 stride 1 pad 1 and 1x1."""
+class Conv2d(_WeightBias):
+    """weight OIHW, bias (O) -- reference modules.py:87-144.  Only the two shapes the UNet uses are executable on the HIP
+    path (3x3 stride 1 pad 1, and 1x1); the other constructor arguments are recorded for repr / compatibility."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  padding_mode="zeros", init_scale=1.):
         super().__init__()
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.kernel_size = pair(kernel_size)
-        self.stride, self.dilation, self.groups = pair(stride), pair(dilation), groups
+        self.in_channels, self.out_channels, self.groups, self.padding_mode = in_channels, out_channels, groups, padding_mode
+        self.kernel_size, self.stride, self.dilation = pair(kernel_size), pair(stride), pair(dilation)
         self.padding = padding if isinstance(padding, str) else pair(padding)
-        self.padding_mode, self.init_scale = padding_mode, init_scale
-        self.weight = nn.Parameter(torch.empty((out_channels, in_channels // groups, *self.kernel_size), dtype=DEFAULT_DTYPE))
-        if bias:
-            self.bias = nn.Parameter(torch.empty((out_channels,), dtype=DEFAULT_DTYPE))
-        else:
-            self.register_parameter("bias", None)
-        self.reset_parameter()
+        self._make((out_channels, in_channels // groups) + self.kernel_size, bias, init_scale)
 
-    def reset_parameter(self):
-        DEFAULT_INITIALIZER(self.weight, scale=self.init_scale)
-        if self.bias is not None:
-            nn.init.zeros_(self.bias)
+    reset_parameter = _WeightBias._init            # (sic: the reference spells it without the plural on Conv2d)
 
     def extra_repr(self):
-        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
-                f"padding={self.padding}")
+        return f"{self.in_channels} -> {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}"
 
 
 class GroupNorm32(nn.Module):
@@ -87,13 +87,14 @@ class GroupNorm32(nn.Module):
 
     def __init__(self, num_channels, num_groups=32, eps=1e-6):
         super().__init__()
-        assert num_channels % num_groups == 0
+        if num_channels % num_groups:
+            raise ValueError(f"{num_channels} channels cannot form {num_groups} groups")
         self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
         self.weight = nn.Parameter(torch.ones(num_channels))
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
     def extra_repr(self):
-        return f"{self.num_groups}, {self.num_channels}, eps={self.eps}"
+        return f"groups={self.num_groups}, channels={self.num_channels}, eps={self.eps}"
 
 
 class OneHot(nn.Module):
