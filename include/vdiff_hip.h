@@ -137,6 +137,13 @@ int vd_softmax_rows_bwd(const float* p, float* dp, int64_t rows, int32_t L, floa
 int vd_nchw_to_nhwc(const float* x, float* y, int32_t nimg, int32_t C, int32_t H, int32_t W, int64_t ldy, void* stream);
 int vd_nhwc_to_nchw(const float* x, int64_t ldx, float* y, int32_t nimg, int32_t C, int32_t H, int32_t W, void* stream);
 
+/* the data formats either side of the path:
+ *   out_u8[b][y][x][c] = uint8(clamp(x*127.5+127.5, 0, 255))   generate.py:149 (quantise + NCHW->HWC pack, on device)
+ *   out[b][c][y][x]    = (u8[b][y][x'][c]/255 - 0.5)/0.5, x' mirrored where flip[b]   datasets.py:115-120 (flip may be NULL) */
+int vd_images_to_uint8_hwc(const float* x_nchw, uint8_t* out_hwc, int32_t n, int32_t C, int32_t HW, void* stream);
+int vd_images_from_uint8_hwc(const uint8_t* in_hwc, const uint8_t* flip, float* out_nchw, int32_t n, int32_t C,
+                             int32_t H, int32_t W, void* stream);
+
 /* ------------------------------------------------------------------ embeddings
  * get_timestep_embedding (functions.py:11-29): fp64 arithmetic, fp32 result [n][dim] */
 int vd_timestep_embedding(const double* t, float* out, int32_t n, int32_t dim, double scale, void* stream);

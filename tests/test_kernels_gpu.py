@@ -360,6 +360,24 @@ def test_layout_roundtrip(H):
     assert torch.equal(z.cpu(), x)
 
 
+def test_uint8_image_formats(H):
+    """the data formats either side of the path: generate.py:149 (export) and datasets.py:115-120 (ingest)"""
+    from v_diffusion.functions import to_uint8_images, from_uint8_images
+    x = rnd(5, 3, 8, 12, seed=1).clamp(-1.3, 1.3)
+    ref = (x * 127.5 + 127.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    got = to_uint8_images(x.to(DEV))
+    assert got.dtype == torch.uint8 and torch.equal(got.cpu(), ref)
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (5, 8, 12, 3), generator=g, dtype=torch.uint8)
+    flip = torch.tensor([1, 0, 1, 0, 0], dtype=torch.bool)
+    t = u8.permute(0, 3, 1, 2).float() / 255.0                       # ToTensor
+    t = torch.where(flip[:, None, None, None], t.flip(-1), t)        # RandomHorizontalFlip (applied before ToTensor; commutes)
+    ref = (t - 0.5) / 0.5                                            # Normalize(0.5, 0.5)
+    got = from_uint8_images(u8.to(DEV), flip.to(DEV))
+    assert torch.equal(got.cpu(), ref)
+    assert torch.equal(from_uint8_images(u8.to(DEV)).cpu(), (u8.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5)
+
+
 def test_timestep_embedding_matches_oracle(H):
     from oracle.unet_ref import timestep_embedding
     t = torch.tensor([0.0, 1e-3, 0.25, 0.5, 0.999, 1.0, 0.123456789], dtype=torch.float64)

@@ -151,7 +151,48 @@ __global__ void multitag_norm_kernel(const float* y, float* out, int n, int ncls
     for (int k = 0; k < ncls; ++k) out[(long long)b * ncls + k] = y[(long long)b * ncls + k] / d;
 }
 
+// generate.py:149  (x*127.5+127.5).clamp(0,255).to(uint8).permute(0,2,3,1): NCHW fp32 -> HWC uint8, one pass
+__global__ void to_uint8_hwc_kernel(const float* x, unsigned char* out, int n, int C, long long HW) {
+    const long long total = (long long)n * HW * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long long bp = idx / C, pix = bp % HW, b = bp / HW;
+        float v = x[(b * C + c) * HW + pix] * 127.5f + 127.5f;
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        out[idx] = (unsigned char)v;                       // truncation, as torch's float -> uint8 cast
+    }
+}
+// datasets.py:115-120  RandomHorizontalFlip -> ToTensor (u8/255) -> Normalize(0.5, 0.5): HWC uint8 -> NCHW fp32, one pass
+__global__ void from_uint8_hwc_kernel(const unsigned char* in, const unsigned char* flip, float* out, int n, int C, int H, int W) {
+    const long long HW = (long long)H * W, total = (long long)n * C * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long pix = idx % HW, bc = idx / HW;
+        const int c = (int)(bc % C);
+        const long long b = bc / C;
+        const int y = (int)(pix / W), xx = (int)(pix % W);
+        const int xs = (flip && flip[b]) ? W - 1 - xx : xx;
+        const float v = (float)in[((b * H + y) * W + xs) * C + c] / 255.0f;
+        out[idx] = (v - 0.5f) / 0.5f;
+    }
+}
+
 }  // namespace
+
+extern "C" int vd_images_to_uint8_hwc(const float* x_nchw, uint8_t* out, int32_t n, int32_t C, int32_t HW, void* stream) {
+    hipLaunchKernelGGL(to_uint8_hwc_kernel, dim3(grid_for((long long)n * C * HW)), dim3(256), 0, (hipStream_t)stream, x_nchw, out,
+                       n, C, (long long)HW);
+    VD_LAUNCH_CHECK("to_uint8_hwc_kernel");
+    return 0;
+}
+extern "C" int vd_images_from_uint8_hwc(const uint8_t* in_hwc, const uint8_t* flip, float* out_nchw, int32_t n, int32_t C,
+                                        int32_t H, int32_t W, void* stream) {
+    hipLaunchKernelGGL(from_uint8_hwc_kernel, dim3(grid_for((long long)n * C * H * W)), dim3(256), 0, (hipStream_t)stream, in_hwc,
+                       flip, out_nchw, n, C, H, W);
+    VD_LAUNCH_CHECK("from_uint8_hwc_kernel");
+    return 0;
+}
 
 extern "C" int vd_axpby(const float* x, int64_t ldx, float alpha, float* y, int64_t ldy, float beta, int64_t rows, int32_t C,
                         void* stream) {

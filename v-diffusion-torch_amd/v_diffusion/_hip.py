@@ -55,6 +55,8 @@ _SIGNATURES = {
     "vd_softmax_rows_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "vd_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "vd_nhwc_to_nchw": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vd_images_to_uint8_hwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_images_from_uint8_hwc": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vd_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _vp]),
     "vd_class_embed": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_class_embed_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -102,7 +104,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise HipError("v_diffusion HIP op received a CPU tensor: the hot path runs on an MI355X only (no CPU fallback)")
-    if t.dtype not in (torch.float32, torch.float64):
+    if t.dtype not in (torch.float32, torch.float64, torch.uint8):
         raise HipError(f"unsupported dtype {t.dtype}")
     return t.data_ptr()
 
@@ -245,6 +247,14 @@ def nchw_to_nhwc(x, y, nimg, Cc, H, W, ldy):
 
 def nhwc_to_nchw(x, ldx, y, nimg, Cc, H, W):
     _check(lib().vd_nhwc_to_nchw(ptr(x), ldx, ptr(y), nimg, Cc, H, W, stream()), "vd_nhwc_to_nchw")
+
+
+def images_to_uint8_hwc(x, out, n, Cc, HW):
+    _check(lib().vd_images_to_uint8_hwc(ptr(x), ptr(out), n, Cc, HW, stream()), "vd_images_to_uint8_hwc")
+
+
+def images_from_uint8_hwc(u8, flip, out, n, Cc, H, W):
+    _check(lib().vd_images_from_uint8_hwc(ptr(u8), ptr(flip), ptr(out), n, Cc, H, W, stream()), "vd_images_from_uint8_hwc")
 
 
 def timestep_embedding(t, out, n, dim, scale=1000.0):
