@@ -365,13 +365,29 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-    const int m0 = blockIdx.y * BM;
-    int n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own 4 MiB L2.
+    // Remapping so that every XCD walks a CONTIGUOUS range of (m-tile, n-tile) pairs puts the n-tiles of one m-tile
+    // (same A rows) and consecutive m-tiles (shared conv halo rows) on one L2, instead of fetching them through the
+    // fabric once per XCD.  Pure speed/traffic choice: any placement is correct (bijective map, guide T1).
+    // (the z index -- split-K slab or batch entry -- is the slowest: all tiles of one slab / batch entry share their
+    // K range or their operands, so they are kept on one XCD too)
+    int tbx = blockIdx.x, tby = blockIdx.y, tbz = blockIdx.z;
+    {
+        const unsigned T = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (T >= 16) {
+            const unsigned q = T / 8, r = T % 8, xcd = lin % 8, slot = lin / 8;
+            const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+            tbx = t % gridDim.x; tby = (t / gridDim.x) % gridDim.y; tbz = t / (gridDim.x * gridDim.y);
+        }
+    }
+    const int m0 = tby * BM;
+    int n0 = tbx * BN;
     int tapN = 0, ci0 = 0;
     if (BK == VD_IM2COL) {
         const int cchN = (p.Cin + BN - 1) / BN;
-        tapN = blockIdx.x / cchN;
-        ci0 = (blockIdx.x % cchN) * BN;
+        tapN = tbx / cchN;
+        ci0 = (tbx % cchN) * BN;
         n0 = tapN * p.Cin + ci0;
     }
     const float* A = p.A;
@@ -380,11 +396,11 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     const float* R = p.R;
     int kt_begin = 0, kt_end = p.kt_total;
     if (SPLITK) {
-        kt_begin = blockIdx.z * p.kt_per_split;
+        kt_begin = tbz * p.kt_per_split;
         kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
-        C += (long long)blockIdx.z * p.slab_stride;
+        C += (long long)tbz * p.slab_stride;
     } else {
-        const int zb = blockIdx.z / p.nh, zh = blockIdx.z % p.nh;
+        const int zb = tbz / p.nh, zh = tbz % p.nh;
         A += zb * p.sAb + zh * p.sAh;
         B += zb * p.sBb + zh * p.sBh;
         C += zb * p.sCb + zh * p.sCh;
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     float csum[MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a) csum[a] = 0.f;
-    const bool do_cs = (AK == VD_COL) && p.colsum != nullptr && blockIdx.x == 0 && (wave & 1) == 0;
+    const bool do_cs = (AK == VD_COL) && p.colsum != nullptr && tbx == 0 && (wave & 1) == 0;
 
     // fragment loads of sub-step s (8 k values): MT + NT LDS reads per wave
     auto load_frags = [&](const float* as, const float* bs, int s, f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             const float v = csum[a] + __shfl_xor(csum[a], 32, 64);
             const int m = m0 + wm + (A2 ? 2 * li + a : 32 * a + li);
             if (lh == 0 && m < p.M) {
-                float* o = p.colsum + (SPLITK ? (long long)blockIdx.z * p.M : 0) + m;
+                float* o = p.colsum + (SPLITK ? (long long)tbz * p.M : 0) + m;
                 *o = (!SPLITK && p.colsum_accumulate) ? *o + v : v;
             }
         }
