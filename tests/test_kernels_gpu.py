@@ -465,3 +465,21 @@ def test_sumsq_adamw_ema(H):
         H.adamw_ema(pd, gd, m, v, ema, ss, 1.0, 2e-4, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, 0.99)
     close(pd, ref.detach(), None, floor=2e-6, name="adamw p")
     close(ema, ema_ref, None, floor=2e-6, name="ema")
+
+
+@pytest.mark.parametrize("knobs", [{"VD_GEMM_KT": "16", "VD_GEMM_TILE": "128"}, {"VD_GEMM_LEGACY": "1"}])
+def test_kernel_variants_in_subprocess(H, knobs):
+    """Two instantiations no oracle-sized case selects by itself: the KT = 16 form of the 128x128 LDS-DMA kernel (picked
+    for launches of >= 2048 workgroups) and the register-staged fallback kernel (picked when a leading dimension exceeds
+    the 32-bit buffer-offset range).  Force each through its knob and re-run the GEMM / conv parity cases in a child
+    process (the knobs are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **knobs)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-q", "-x", "--no-header",
+                        "-p", "no:cacheprovider", "-k", "gemm_kinds or conv3x3_forward or conv3x3_dgrad or conv3x3_wgrad or batched_heads or test_gemm_splitk or colsum"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
