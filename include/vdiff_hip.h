@@ -57,6 +57,9 @@ typedef struct vd_gemm_desc {
     int32_t tile;               /* 0 = auto; 128, 64, 12864 (128x64), 64128 (64x128) force the block tile */
     float*  colsum;             /* optional, VD_COL A only: colsum[m] (+)= sum_k A[k][m] (bias gradient of a */
     int32_t colsum_accumulate;  /*   weight-gradient GEMM, computed from the tiles already staged); batch = 1  */
+    float*  stats;              /* optional, forward launches: GroupNorm partials of the OUTPUT rows, laid out  */
+    int32_t stats_hw;           /*   [image][chunk][2][N] with chunk = BM/2 rows (BM from vd_gemm_last_tile);    */
+                                /*   stats_hw = rows (pixels) per image; finalize: vd_gn_stats_from_partials     */
 } vd_gemm_desc;
 
 /* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two
@@ -73,7 +76,8 @@ int vd_gemm_last_tile(void);
  * Cin must be a multiple of 4 (pad 3 -> 4); only co < Cout is written. */
 int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, const float* bias,
                const float* res, int64_t ldres, float* y, int64_t ldy,
-               int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate, void* stream);
+               int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate,
+               float* stats_part /* optional: GroupNorm partials of y, see vd_gemm_desc.stats */, void* stream);
 
 /* weight (and bias) gradient of the same convolution, summed over the whole batch (autograd of F.conv2d):
  *   dw_oihw[co][ci][tap] (+)= sum_{b,y,x} dy[b,y,x,co] * xin[b,y+dy,x+dx,ci]      co < Cout_w, ci < Cin_w
@@ -99,6 +103,11 @@ enum { VD_RS_NONE = 0, VD_RS_DOWN = 1, VD_RS_UP = 2 };
 size_t vd_gn_ws_bytes(int32_t nimg, int32_t HW, int32_t C);
 int vd_gn_stats(const float* x, int64_t ldx, int32_t nimg, int32_t HW, int32_t C, int32_t G, float eps,
                 float* stats, float* ws, size_t ws_bytes, void* stream);
+
+/* the same statistics from the partial sums a producer epilogue left behind (vd_gemm_desc.stats / vd_conv3x3 stats_part):
+ * the normalised tensor is the channel concatenation [C1 | C2] of up to two produced tensors (C2 = 0: one source) */
+int vd_gn_stats_from_partials(const float* part1, int32_t C1, int32_t chunks1, const float* part2, int32_t C2, int32_t chunks2,
+                              int32_t nimg, int32_t HW, int32_t G, float eps, float* stats, void* stream);
 
 /* y = resample( dropout( act( (1+scale) * GN(x) + shift ) ) )
  * film: [nimg][2C] (shift first, scale second, unet.py:145) or NULL; act: 1 = SiLU, 0 = identity;

@@ -261,6 +261,43 @@ def test_gn_forward_backward(H, case):
         close(dfilm, df64, df32, slack=6, floor=5e-6, name="dfilm")
 
 
+@pytest.mark.parametrize("case", [(3, 8, 8, 64, 96, 0), (2, 16, 16, 32, 256, 0), (2, 32, 32, 64, 64, 64), (1, 8, 16, 32, 192, 32)])
+def test_gn_stats_from_producer_epilogues(H, case):
+    """GroupNorm statistics assembled from the partial sums the producing conv / 1x1 GEMM epilogues leave behind, for a
+    single source and for the channel concatenation of two sources (the virtual concat of unet.py:315)"""
+    nimg, Hh, Ww, Cin, C1, C2 = case
+    HW = Hh * Ww
+    x = rnd(nimg, Cin, Hh, Ww, seed=1)
+    w1, b1 = rnd(C1, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), rnd(C1, seed=3)
+    res = rnd(nimg, C1, Hh, Ww, seed=4)
+    y1 = F.conv2d(x.double(), w1.double(), b1.double(), padding=1) + res.double()
+    wf = torch.empty(C1, 9, Cin, device=DEV)
+    H.pack_conv3x3(w1.to(DEV), C1, Cin, wf=wf, Cin_p=Cin)
+    Ct = C1 + C2
+    buf = torch.zeros(nimg, Hh, Ww, Ct, device=DEV)
+    part1 = torch.full((H.stats_part_numel(nimg, HW, C1),), 7.0, device=DEV)
+    H.conv3x3(nhwc(x), Cin, wf, b1.to(DEV), buf[..., :C1], Ct, nimg, Hh, Ww, Cin, C1, res=nhwc(res), ldres=C1, stats_part=part1)
+    parts = [(part1, C1, HW // (H.last_row_tile() // 2))]
+    ref = y1
+    if C2:
+        w2, b2 = rnd(C2, Cin, seed=5, scale=Cin ** -0.5), rnd(C2, seed=6)          # second source: a 1x1 conv (plain GEMM)
+        y2 = F.conv2d(x.double(), w2.double()[:, :, None, None], b2.double())
+        part2 = torch.full((H.stats_part_numel(nimg, HW, C2),), 7.0, device=DEV)
+        H.gemm(nhwc(x), w2.to(DEV), buf[0, 0, 0, C1:], nimg * HW, C2, Cin, lda=Cin, ldb=Cin, ldc=Ct, bias=b2.to(DEV), stats=part2,
+               stats_hw=HW)
+        parts.append((part2, C2, HW // (H.last_row_tile() // 2)))
+        ref = torch.cat([y1, y2], 1)
+    stats = torch.empty(nimg, 32, 2, device=DEV)
+    H.gn_stats_from_partials(parts, nimg, HW, stats)
+    direct = torch.empty(nimg, 32, 2, device=DEV)
+    H.gn_stats(buf, Ct, nimg, HW, Ct, direct)
+    g = ref.reshape(nimg, 32, -1)
+    mean, var = g.mean(-1), g.var(-1, unbiased=False)
+    close(stats[..., 0], mean, None, floor=2e-6, name="mean")
+    close(stats[..., 1], 1 / torch.sqrt(var + 1e-6), None, floor=5e-6, name="rstd")
+    close(direct[..., 1], 1 / torch.sqrt(var + 1e-6), None, floor=5e-6, name="rstd direct")
+
+
 @pytest.mark.parametrize("rs", [0, 1, 2])
 def test_plain_resample_and_backward(H, rs):
     nimg, Cc, Hh, Ww = 2, 64, 8, 8

@@ -35,6 +35,7 @@ struct GemmArgs {
     long long slab_stride;
     float* colsum; int colsum_accumulate;     // COL-kind A only: colsum[m] (+)= sum_k A[k][m]  (bias gradients ride along)
     int probe;                                // timing experiments only (VD_GEMM_PROBE): bit0/bit1 drop the A/B tile loads
+    float* stats; int stats_hw;               // GroupNorm partials of the OUTPUT: [img][chunk][2][N], chunk = BM/2 output rows
 };
 
 __device__ __forceinline__ int row_swz(int row, int chunk) { return row * KT + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
         if (!nok) continue;
         const float bv = (!SPLITK && p.bias) ? p.bias[n] : 0.f;
+        float st1 = 0.f, st2 = 0.f;           // per-column sum / sum of squares of this wave's BM/2 output rows
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -309,8 +311,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     v = v * p.alpha + bv;
                     if (R) v += R[(long long)m * p.ldr + n];
                     if (p.accumulate) v += C[(long long)m * p.ldc + n];
+                    st1 += v; st2 += v * v;
                 }
                 C[(long long)m * p.ldc + n] = v;
+            }
+        }
+        // GroupNorm statistics of the tensor being written, for the norm that consumes it next (saves that norm's read
+        // pass): the two lane halves hold complementary rows of the wave's BM/2-row slab, which lies inside one image
+        if (!SPLITK && p.stats) {
+            st1 += __shfl_xor(st1, 32, 64);
+            st2 += __shfl_xor(st2, 32, 64);
+            const int mrow = m0 + wm;
+            if (lh == 0 && mrow < p.M) {
+                const int chunks = p.stats_hw / (BM / 2);
+                float* o = p.stats + ((long long)(mrow / p.stats_hw) * chunks + (mrow % p.stats_hw) / (BM / 2)) * 2 * p.N + n;
+                o[0] = st1; o[p.N] = st2;
             }
         }
     }
@@ -651,6 +666,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
         if (!nok) continue;
         const float bv = (!SPLITK && p.bias) ? p.bias[n] : 0.f;
+        float st1 = 0.f, st2 = 0.f;           // per-column sum / sum of squares of this wave's BM/2 output rows
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -663,8 +679,21 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                     v = v * p.alpha + bv;
                     if (R) v += R[(long long)m * p.ldr + n];
                     if (p.accumulate) v += C[(long long)m * p.ldc + n];
+                    st1 += v; st2 += v * v;
                 }
                 C[(long long)m * p.ldc + n] = v;
+            }
+        }
+        // GroupNorm statistics of the tensor being written, for the norm that consumes it next (saves that norm's read
+        // pass): the two lane halves hold complementary rows of the wave's BM/2-row slab, which lies inside one image
+        if (!SPLITK && p.stats) {
+            st1 += __shfl_xor(st1, 32, 64);
+            st2 += __shfl_xor(st2, 32, 64);
+            const int mrow = m0 + wm;
+            if (lh == 0 && mrow < p.M) {
+                const int chunks = p.stats_hw / (BM / 2);
+                float* o = p.stats + ((long long)(mrow / p.stats_hw) * chunks + (mrow % p.stats_hw) / (BM / 2)) * 2 * p.N + n;
+                o[0] = st1; o[p.N] = st2;
             }
         }
     }
@@ -828,6 +857,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.H = d.H; a.W = d.W; a.Cin = d.Cin;
     a.kt_total = 0; a.kt_per_split = 0; a.slab_stride = 0;
     a.colsum = d.colsum; a.colsum_accumulate = d.colsum_accumulate;
+    a.stats = d.stats; a.stats_hw = d.stats_hw;
     { static const char* e = getenv("VD_GEMM_PROBE"); a.probe = e ? atoi(e) : 0; }
     VD_REQUIRE(!(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
 
@@ -836,6 +866,11 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     const long long nm = (d.M + tbm - 1) / tbm;
     const long long nn = wgrad ? 9LL * ((d.Cin + tbn - 1) / tbn) : (d.N + tbn - 1) / tbn;
     VD_REQUIRE(nm <= 65535, "vd_gemm: too many row tiles (%lld)", nm);
+    if (d.stats) {
+        VD_REQUIRE(batch == 1 && splitk == 1 && !wgrad && bk == VD_ROW && ak != VD_COL, "vd_gemm: output statistics need a plain forward launch");
+        VD_REQUIRE(d.stats_hw > 0 && d.stats_hw % (tbm / 2) == 0 && d.M % d.stats_hw == 0,
+                   "vd_gemm: output statistics need H*W (%d) to be a multiple of half the row tile (%d)", d.stats_hw, tbm / 2);
+    }
     const int ktile = ktile_for(a, tile, nm * nn * batch, splitk > 1);
     a.kt_total = conv ? 9 * ((d.Cin + ktile - 1) / ktile) : (d.K + ktile - 1) / ktile;
     a.kt_per_split = a.kt_total;
@@ -889,7 +924,7 @@ extern "C" int vd_gemm(const vd_gemm_desc* d, void* stream) {
 
 extern "C" int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, const float* bias, const float* res,
                           int64_t ldres, float* y, int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t Cin,
-                          int32_t Cout, int32_t accumulate, void* stream) {
+                          int32_t Cout, int32_t accumulate, float* stats_part, void* stream) {
     VD_REQUIRE(Cin % 4 == 0, "vd_conv3x3: Cin must be a multiple of 4 (got %d)", Cin);
     vd_gemm_desc d = {};
     d.A = xin; d.B = wpack; d.C = y; d.bias = bias; d.R = res;
@@ -898,6 +933,8 @@ extern "C" int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, con
     d.lda = ldx; d.ldb = 9LL * Cin; d.ldc = ldy; d.ldr = ldres;
     d.batch = 1; d.nh = 1; d.alpha = 1.f; d.accumulate = accumulate;
     d.H = H; d.W = W; d.Cin = Cin;
+    d.stats = stats_part; d.stats_hw = H * W;
+    if (stats_part && (H * W) % 64 != 0) d.tile = 64;      // 64-row tiles (32-row slabs) whenever the image allows only that
     return run_gemm(d, (hipStream_t)stream);
 }
 

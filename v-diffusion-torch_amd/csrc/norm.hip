@@ -127,6 +127,31 @@ __global__ void gn_stats_finalize_kernel(const float* part, int nimg, int chunks
     stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// statistics from the partials that producer GEMM epilogues left behind (vd_gemm / vd_conv3x3 `stats`): the normalised
+// tensor is the channel concatenation of up to two produced tensors, each with its own chunk size
+__global__ void gn_stats_from_partials_kernel(const float* p1, int C1, int ch1, const float* p2, int C2, int ch2, int nimg,
+                                              int G, long long HW, float eps, float* stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nimg * G) return;
+    const int b = idx / G, g = idx % G, C = C1 + C2, cg = C / G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+        const bool first = c < C1;
+        const float* pp = first ? p1 : p2;
+        const int Cs = first ? C1 : C2, cs = first ? c : c - C1, chunks = first ? ch1 : ch2;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const float* q = pp + ((long long)(b * chunks + ch) * 2) * Cs + cs;
+            s1 += (double)q[0]; s2 += (double)q[Cs];
+        }
+    }
+    const double n = (double)cg * (double)HW;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * idx] = (float)mean;
+    stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // coef[b][0][c] = rstd*gamma*(1+scale)   coef[b][1][c] = (beta - mean*rstd*gamma)*(1+scale) + shift
 // coef[b][2][c] = rstd                   coef[b][3][c] = -mean*rstd
 __global__ void gn_coef_kernel(const float* stats, const float* gamma, const float* beta, const float* film, int nimg,
@@ -358,6 +383,17 @@ extern "C" int vd_gn_stats(const float* x, int64_t ldx, int32_t nimg, int32_t HW
     hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3((nimg * G + 127) / 128), dim3(128), 0, st, ws, nimg, p.chunks, C, G,
                        (long long)HW, eps, stats);
     VD_LAUNCH_CHECK("gn_stats_finalize_kernel");
+    return 0;
+}
+
+extern "C" int vd_gn_stats_from_partials(const float* part1, int32_t C1, int32_t chunks1, const float* part2, int32_t C2,
+                                         int32_t chunks2, int32_t nimg, int32_t HW, int32_t G, float eps, float* stats,
+                                         void* stream) {
+    VD_REQUIRE(part1 && C1 > 0 && chunks1 > 0 && (C1 + C2) % G == 0, "vd_gn_stats_from_partials: bad arguments");
+    VD_REQUIRE(C2 == 0 || (part2 && chunks2 > 0), "vd_gn_stats_from_partials: second source incomplete");
+    hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3((nimg * G + 127) / 128), dim3(128), 0, (hipStream_t)stream, part1, C1,
+                       chunks1, part2, C2, chunks2, nimg, G, (long long)HW, eps, stats);
+    VD_LAUNCH_CHECK("gn_stats_from_partials_kernel");
     return 0;
 }
 

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("sCb", _i64), ("sCh", _i64), ("sRb", _i64), ("sRh", _i64),
                 ("alpha", _f32), ("accumulate", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32),
                 ("splitk", _i32), ("ws", _vp), ("ws_bytes", _i64), ("tile", _i32),
-                ("colsum", _vp), ("colsum_accumulate", _i32)]
+                ("colsum", _vp), ("colsum_accumulate", _i32), ("stats", _vp), ("stats_hw", _i32)]
 
 
 _SIGNATURES = {
@@ -37,7 +37,8 @@ _SIGNATURES = {
     "vd_last_error": (C.c_char_p, []),
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_last_tile": (C.c_int, []),
-    "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_pack_conv3x3": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
@@ -157,7 +158,7 @@ def workspace(nbytes, device, tag="default"):
 # ----------------------------------------------------------------------------------------------- wrappers
 def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None, R=None, ldr=0, batch=1, nh=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), alpha=1.0, accumulate=False, splitk=1, tile=0, colsum=None,
-         colsum_accumulate=False):
+         colsum_accumulate=False, stats=None, stats_hw=0):
     d = GemmDesc()
     d.A, d.B, d.C, d.bias, d.R = ptr(A), ptr(B), ptr(Cm), ptr(bias), ptr(R)
     d.M, d.N, d.K, d.a_kind, d.b_kind = M, N, K, a_kind, b_kind
@@ -167,6 +168,7 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     d.alpha, d.accumulate = alpha, int(accumulate)
     d.splitk, d.tile = splitk, tile
     d.colsum, d.colsum_accumulate = ptr(colsum), int(colsum_accumulate)
+    d.stats, d.stats_hw = ptr(stats), stats_hw
     if splitk > 1:
         ws = workspace(splitk * (M * N + M) * 4, A.device, "splitk")
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -175,10 +177,27 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
         _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
 
 
-def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False):
+def last_row_tile():
+    """BM of the calling thread's last vd_gemm / vd_conv3x3 launch (chunk size of its output statistics = BM/2)"""
+    return (lib().vd_gemm_last_tile() // 1000) % 1000
+
+
+def stats_part_numel(nimg, HW, Cc):
+    """floats needed for the GroupNorm partials of an (nimg, HW, Cc) output, whatever row tile the launch picks"""
+    return nimg * max(HW // 32, 1) * 2 * Cc
+
+
+def gn_stats_from_partials(parts, nimg, HW, stats, G=32, eps=1e-6):
+    """parts: [(part, C, chunks)] for one or two channel-concatenated sources"""
+    (p1, c1, k1), (p2, c2, k2) = parts[0], (parts[1] if len(parts) > 1 else (None, 0, 0))
+    _check(lib().vd_gn_stats_from_partials(ptr(p1), c1, k1, ptr(p2), c2, k2, nimg, HW, G, eps, ptr(stats), stream()),
+           "vd_gn_stats_from_partials")
+
+
+def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):
     with _Timed("gemm_dma_kernel<{tile}, 2, 0, false, {kt}>", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3(ptr(x), ldx, ptr(wpack), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
-                                int(accumulate), stream()), "vd_conv3x3")
+                                int(accumulate), ptr(stats_part), stream()), "vd_conv3x3")
 
 
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):

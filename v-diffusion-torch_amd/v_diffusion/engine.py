@@ -126,6 +126,23 @@ class UNetEngine:
     def _res_of(self, level, H0, W0):
         return H0 >> level, W0 >> level
 
+    # ---- GroupNorm statistics ride on the producer: the conv / 1x1 epilogue that writes a tensor also leaves per-
+    # (image, row-chunk, channel) sums behind, and the consuming norm only runs the tiny finalize (no read pass)
+    def _part(self, ref, nimg, HW, C):
+        if HW % 32:
+            return None                                   # tiny images: the norm computes its own statistics
+        return torch.empty(H.stats_part_numel(nimg, HW, C), dtype=torch.float32, device=ref.device)
+
+    @staticmethod
+    def _parts(part, C, HW):
+        return None if part is None else [(part, C, HW // (H.last_row_tile() // 2))]
+
+    def _stats(self, x, x_parts, B, HW, C, stats):
+        if x_parts is not None:
+            H.gn_stats_from_partials(x_parts, B, HW, stats, GROUPS, EPS)
+        else:
+            H.gn_stats(x, _ld(x), B, HW, C, stats, GROUPS, EPS)
+
     def _pack_f(self, w, cin_p=None):
         co, ci = w.shape[0], w.shape[1]
         cin_p = cin_p or ci
@@ -212,20 +229,22 @@ class UNetEngine:
         self._linear_bwd(te0, l0.weight, dh0, G["time_embed.0.weight"], G["time_embed.0.bias"], None)
 
     # ------------------------------------------------------------------------------------------ residual block
-    def _res_fwd(self, blk, mod, prefix, x, ta, dest, p_drop, seed, tape):
+    def _res_fwd(self, blk, mod, prefix, x, ta, dest, p_drop, seed, tape, x_parts=None):
         B, Hh, Ww, Cin, ldx = _chk(x)
         Cout, rs = blk.cout, blk.rs
         Ho, Wo = (Hh // 2, Ww // 2) if rs == H.RS_DOWN else ((Hh * 2, Ww * 2) if rs == H.RS_UP else (Hh, Ww))
         stats1, coef1 = self._new(x, B, GROUPS, 2), self._new(x, B, 4, Cin)
-        H.gn_stats(x, ldx, B, Hh * Ww, Cin, stats1, GROUPS, EPS)
+        self._stats(x, x_parts, B, Hh * Ww, Cin, stats1)
         a1 = self._new(x, B, Ho, Wo, Cin)
         H.gn_apply(x, ldx, stats1, mod.norm1.weight, mod.norm1.bias, None, 1, 0.0, 0, rs, a1, Cin, B, Hh, Ww, Cin, coef1, GROUPS)
         h1 = self._new(x, B, Ho, Wo, Cout)
-        H.conv3x3(a1, Cin, self._pack_f(mod.conv1.weight), mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout)
+        ph = self._part(x, B, Ho * Wo, Cout)
+        H.conv3x3(a1, Cin, self._pack_f(mod.conv1.weight), mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout, stats_part=ph)
+        h1_parts = self._parts(ph, Cout, Ho * Wo)
         film = self._new(x, B, 2 * Cout)
         self._linear(ta, mod.fc.weight, mod.fc.bias, film)
         stats2, coef2 = self._new(x, B, GROUPS, 2), self._new(x, B, 4, Cout)
-        H.gn_stats(h1, Cout, B, Ho * Wo, Cout, stats2, GROUPS, EPS)
+        self._stats(h1, h1_parts, B, Ho * Wo, Cout, stats2)
         a2 = self._new(x, B, Ho, Wo, Cout)
         H.gn_apply(h1, Cout, stats2, mod.norm2.weight, mod.norm2.bias, film, 1, p_drop, seed, H.RS_NONE, a2, Cout, B, Ho, Wo, Cout,
                    coef2, GROUPS)
@@ -241,11 +260,14 @@ class UNetEngine:
             H.gemm(xs, w, sk, B * Ho * Wo, Cout, Cin, a_kind=H.ROW, b_kind=H.ROW, lda=_ld(xs), ldb=Cin, ldc=Cout, bias=mod.skip.bias)
         else:
             sk = xs
+        pd = self._part(x, B, Ho * Wo, Cout)
         H.conv3x3(a2, Cout, self._pack_f(mod.conv2.weight), mod.conv2.bias, dest, _ld(dest), B, Ho, Wo, Cout, Cout, res=sk,
-                  ldres=_ld(sk))
+                  ldres=_ld(sk), stats_part=pd)
+        out_parts = self._parts(pd, Cout, Ho * Wo)
         if tape is not None:
             tape[prefix] = dict(x=x, coef1=coef1, a1=a1, h1=h1, coef2=coef2, a2=a2, film=film, xs=xs if has_skip else None,
                                 seed=seed, p=p_drop, ta=ta)
+        return out_parts
 
     def _res_bwd(self, blk, mod, prefix, ctx, dy, dx, dx_accumulate, dta, G):
         x, a1, h1, a2, film = ctx["x"], ctx["a1"], ctx["h1"], ctx["a2"], ctx["film"]
@@ -296,12 +318,12 @@ class UNetEngine:
         self._linear_bwd(ta, mod.fc.weight, dfilm, G[prefix + ".fc.weight"], G[prefix + ".fc.bias"], dta, dx_accumulate=True)
 
     # ------------------------------------------------------------------------------------------ attention block
-    def _attn_fwd(self, mod, prefix, x, dest, tape):
+    def _attn_fwd(self, mod, prefix, x, dest, tape, x_parts=None):
         B, Hh, Ww, C, ldx = _chk(x)
         L, nh, hd = Hh * Ww, mod.num_heads, mod.head_dim
         hid = nh * hd
         stats, coef = self._new(x, B, GROUPS, 2), self._new(x, B, 4, C)
-        H.gn_stats(x, ldx, B, L, C, stats, GROUPS, EPS)
+        self._stats(x, x_parts, B, L, C, stats)
         xn = self._new(x, B, Hh, Ww, C)
         H.gn_apply(x, ldx, stats, mod.norm.weight, mod.norm.bias, None, 0, 0.0, 0, H.RS_NONE, xn, C, B, Hh, Ww, C, coef, GROUPS)
         qkv = self._new(x, B, L, 3 * hid)
@@ -317,10 +339,15 @@ class UNetEngine:
         O = self._new(x, B, L, hid)
         H.gemm(S, v, O, L, hd, L, a_kind=H.ROW, b_kind=H.COL, lda=L, ldb=ld, ldc=hid, batch=B * nh, nh=nh, sA=(nh * L * L, L * L),
                sB=(L * ld, hd), sC=(L * hid, hd))
+        pd = self._part(x, B, L, C)
+        if pd is not None and L % 64:
+            pd = None                                     # the plain GEMM picks its own row tile: only ask when any tile fits
         H.gemm(O, mod.proj_out.weight, dest, B * L, C, hid, a_kind=H.ROW, b_kind=H.ROW, lda=hid, ldb=hid, ldc=_ld(dest),
-               bias=mod.proj_out.bias, R=x, ldr=ldx)
+               bias=mod.proj_out.bias, R=x, ldr=ldx, stats=pd, stats_hw=L)
+        out_parts = self._parts(pd, C, L)
         if tape is not None:
             tape[prefix] = dict(x=x, coef=coef, xn=xn, qkv=qkv, P=S, O=O)
+        return out_parts
 
     def _attn_bwd(self, mod, prefix, ctx, dy, dx, dx_accumulate, G):
         x, xn, qkv, P, O = ctx["x"], ctx["xn"], ctx["qkv"], ctx["P"], ctx["O"]
@@ -388,36 +415,46 @@ class UNetEngine:
 
         p0 = self.pushes[0]
         d = dest_of(("cat", p0[2], p0[3], p0[1]), H0, W0)
-        H.conv3x3(x4, cip, self._pack_f(m.in_conv.weight, cip), m.in_conv.bias, d, _ld(d), B, H0, W0, cip, m.hid_channels)
+        pp = self._part(x_nchw, B, H0 * W0, m.hid_channels)
+        H.conv3x3(x4, cip, self._pack_f(m.in_conv.weight, cip), m.in_conv.bias, d, _ld(d), B, H0, W0, cip, m.hid_channels,
+                  stats_part=pp)
+        cat_parts = {p0[2]: {p0[3]: self._parts(pp, m.hid_channels, H0 * W0)}}      # consumer block -> {channel offset: partials}
         hs_top, h = d, None
+        top_parts, h_parts = cat_parts[p0[2]][p0[3]], None
         for bi, b in enumerate(self.plan):
             if b.kind == "down":
-                inp = hs_top
+                inp, inp_parts = hs_top, top_parts
             elif b.kind in ("mid", "midattn"):
-                inp = hs_top if h is None else h
+                inp, inp_parts = (hs_top, top_parts) if h is None else (h, h_parts)
+            elif b.consumes:
+                inp = cats[bi]
+                pa, pb = cat_parts.get(bi, {}).get(0), cat_parts.get(bi, {}).get(b.ch_h)
+                inp_parts = pa + pb if (pa is not None and pb is not None) else None
             else:
-                inp = cats[bi] if b.consumes else h
+                inp, inp_parts = h, h_parts
             _, ih, iw, _, _ = _chk(inp)
             oh, ow = (ih // 2, iw // 2) if b.rs == H.RS_DOWN else ((ih * 2, iw * 2) if b.rs == H.RS_UP else (ih, iw))
             spec = b.dest if b.dest[0] == "cat" else ("plain", b.cout)
             out = dest_of(spec, oh, ow)
             if b.kind == "midattn":
-                self._attn_fwd(b.att, b.prefix, inp, out, tape)
+                out_parts = self._attn_fwd(b.att, b.prefix, inp, out, tape, inp_parts)
             elif b.att is not None:
                 mid = self._new(x_nchw, B, oh, ow, b.cout)
-                self._res_fwd(b, b.res, b.prefix + ".0", inp, ta, mid, p_drop, base_seed + 2 * bi + 1, tape)
-                self._attn_fwd(b.att, b.prefix + ".1", mid, out, tape)
+                mid_parts = self._res_fwd(b, b.res, b.prefix + ".0", inp, ta, mid, p_drop, base_seed + 2 * bi + 1, tape, inp_parts)
+                out_parts = self._attn_fwd(b.att, b.prefix + ".1", mid, out, tape, mid_parts)
             else:
-                self._res_fwd(b, b.res, b.prefix, inp, ta, out, p_drop, base_seed + 2 * bi + 1, tape)
+                out_parts = self._res_fwd(b, b.res, b.prefix, inp, ta, out, p_drop, base_seed + 2 * bi + 1, tape, inp_parts)
+            if spec[0] == "cat":
+                cat_parts.setdefault(spec[1], {})[spec[2]] = out_parts
             if b.kind == "down":
-                hs_top = out
+                hs_top, top_parts = out, out_parts
             else:
-                h = out
+                h, h_parts = out, out_parts
         # out_conv: GN -> SiLU -> 3x3
         C0 = m.hid_channels * m.ch_multipliers[0]
         gn, conv = m.out_conv[0], m.out_conv[2]
         stats, coef = self._new(h, B, GROUPS, 2), self._new(h, B, 4, C0)
-        H.gn_stats(h, _ld(h), B, H0 * W0, C0, stats, GROUPS, EPS)
+        self._stats(h, h_parts, B, H0 * W0, C0, stats)
         a = self._new(h, B, H0, W0, C0)
         H.gn_apply(h, _ld(h), stats, gn.weight, gn.bias, None, 1, 0.0, 0, H.RS_NONE, a, C0, B, H0, W0, C0, coef, GROUPS)
         co = m.out_channels
