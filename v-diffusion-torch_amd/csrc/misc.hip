@@ -67,6 +67,43 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* s, long long r
     for (int j = lane; j < L; j += 64) p[j] *= inv;
 }
 
+// register-resident forms for the row lengths the UNet produces (L = 64 * NPL): one read and one write of the row
+template <int NPL>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* s, long long rows) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* p = s + row * (64 * NPL);
+    float v[NPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { v[k] = p[lane + 64 * k]; mx = fmaxf(mx, v[k]); }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { v[k] = __expf(v[k] - mx); sum += v[k]; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) p[lane + 64 * k] = v[k] * inv;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_reg_kernel(const float* pm, float* dp, long long rows, float alpha) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = pm + row * (64 * NPL);
+    float* d = dp + row * (64 * NPL);
+    float pv[NPL], dv[NPL];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { pv[k] = p[lane + 64 * k]; dv[k] = d[lane + 64 * k]; dot += pv[k] * dv[k]; }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) d[lane + 64 * k] = alpha * pv[k] * (dv[k] - dot);
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* pm, float* dp, long long rows, int L, float alpha) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -218,13 +255,25 @@ extern "C" int vd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n
 extern "C" int vd_softmax_rows(float* s, int64_t rows, int32_t L, void* stream) {
     if (rows <= 0) return 0;
     VD_REQUIRE(L > 0, "vd_softmax_rows: L must be positive");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, s, rows, L);
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (L == 64) hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, grid, blk, 0, st, s, (long long)rows);
+    else if (L == 256) hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, grid, blk, 0, st, s, (long long)rows);
+    else if (L == 1024) hipLaunchKernelGGL(softmax_rows_reg_kernel<16>, grid, blk, 0, st, s, (long long)rows);
+    else if (L == 4096) hipLaunchKernelGGL(softmax_rows_reg_kernel<64>, grid, blk, 0, st, s, (long long)rows);
+    else hipLaunchKernelGGL(softmax_rows_kernel, grid, blk, 0, st, s, rows, L);
     VD_LAUNCH_CHECK("softmax_rows_kernel");
     return 0;
 }
 extern "C" int vd_softmax_rows_bwd(const float* p, float* dp, int64_t rows, int32_t L, float alpha, void* stream) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p, dp, rows, L, alpha);
+    const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (L == 64) hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<1>, grid, blk, 0, st, p, dp, (long long)rows, alpha);
+    else if (L == 256) hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<4>, grid, blk, 0, st, p, dp, (long long)rows, alpha);
+    else if (L == 1024) hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<16>, grid, blk, 0, st, p, dp, (long long)rows, alpha);
+    else if (L == 4096) hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<64>, grid, blk, 0, st, p, dp, (long long)rows, alpha);
+    else hipLaunchKernelGGL(softmax_rows_bwd_kernel, grid, blk, 0, st, p, dp, rows, L, alpha);
     VD_LAUNCH_CHECK("softmax_rows_bwd_kernel");
     return 0;
 }

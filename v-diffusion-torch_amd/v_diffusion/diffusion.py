@@ -394,6 +394,18 @@ class GaussianDiffusion:
             return self._sample_loop_graph(denoise_fn, tuple(shape), x_t, y_in, cfg, device, generator, use_ddim), []
         x_next = torch.empty_like(x_t)
         preds = []
+        net = getattr(denoise_fn, "module", denoise_fn)
+        eng = net.engine() if hasattr(net, "engine") else None
+        if eng is not None:
+            eng.pack_cache = {}                                # the weights do not change inside one reverse chain
+        try:
+            return self._eager_chain(denoise_fn, x_t, x_in, x_in_next, x_next, y_in, cfg, B, T, device, generator, use_ddim,
+                                     pred_freq, preds)
+        finally:
+            if eng is not None:
+                eng.pack_cache = None
+
+    def _eager_chain(self, denoise_fn, x_t, x_in, x_in_next, x_next, y_in, cfg, B, T, device, generator, use_ddim, pred_freq, preds):
         for ti in reversed(range(T)):
             t_in = torch.full((B * (1 + cfg),), (ti + 1) / T, dtype=F64, device=device)
             step_noise = torch.empty_like(x_t).normal_(generator=generator)      # drawn every step, also for DDIM (:389)

@@ -117,6 +117,9 @@ class UNetEngine:
                 nxt = plan[bi + 1] if bi + 1 < len(plan) else None
                 b.dest = ("cat", bi + 1, 0, b.cout) if (nxt is not None and nxt.consumes) else ("plain",)
         self.levels = levels
+        # forward weight packs kept across calls while a sampler holds the weights fixed (set to {} by the sampling loop,
+        # None otherwise: training repacks every step because the optimizer rewrites the weights)
+        self.pack_cache = None
 
     # ------------------------------------------------------------------------------------------ small helpers
     @staticmethod
@@ -144,10 +147,15 @@ class UNetEngine:
             H.gn_stats(x, _ld(x), B, HW, C, stats, GROUPS, EPS)
 
     def _pack_f(self, w, cin_p=None):
+        cache = self.pack_cache
+        if cache is not None and id(w) in cache:
+            return cache[id(w)]
         co, ci = w.shape[0], w.shape[1]
         cin_p = cin_p or ci
         wf = self._new(w, co, 9, cin_p)
         H.pack_conv3x3(w, co, ci, wf=wf, Cin_p=cin_p)
+        if cache is not None:
+            cache[id(w)] = wf
         return wf
 
     def _pack_d(self, w, cout_p=None):
