@@ -410,3 +410,33 @@ def test_graph_sampler_equals_eager(vd):
     a = gd.p_sample(model, (B, 3, R, R), label=y, device=DEV, seed=5, use_graph=False)
     b = gd.p_sample(model, (B, 3, R, R), label=y, device=DEV, seed=5, use_graph=True)
     assert torch.equal(a, b)
+
+
+def test_sampler_properties_full_size(vd):
+    """BASELINE-size sampler properties (no oracle at this size): (i) classifier-free guidance with identical conditional
+    and unconditional rows (label 0 everywhere) is the unguided chain -- the guided mean is mean + w*(mean - mean) -- up to
+    fp32 rounding (the doubled batch may pick other tile shapes / statistics chunk sizes, i.e. another summation order);
+    (ii) seeded chains are reproducible bit for bit; (iii) an empty batch passes through."""
+    from oracle.cases import CIFAR_COND
+    torch.manual_seed(0)
+    model = vd.UNet(**CIFAR_COND)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.ndim >= 2 and float(p.abs().max()) == 0:
+                p.normal_(0, p[0].numel() ** -0.5)
+    model.to(DEV).eval()
+    B, T = 48, 2
+    sched = vd.get_logsnr_schedule("cosine")
+    zeros = torch.zeros((B,), device=DEV)
+    for ddim, vt in ((True, "fixed_large"), (False, "fixed_medium")):
+        g1 = vd.GaussianDiffusion(sched, T, "v", vt, "snr_trunc", "mse", intp_frac=0.3, w_guide=1.5)
+        g0 = vd.GaussianDiffusion(sched, T, "v", vt, "snr_trunc", "mse", intp_frac=0.3, w_guide=0.0)
+        a = g1.p_sample(model, (B, 3, 32, 32), label=zeros, device=DEV, seed=7, use_ddim=ddim)
+        b = g0.p_sample(model, (B, 3, 32, 32), label=zeros, device=DEV, seed=7, use_ddim=ddim)
+        c = g1.p_sample(model, (B, 3, 32, 32), label=zeros, device=DEV, seed=7, use_ddim=ddim)
+        assert torch.equal(a, c), "seeded chain not reproducible"
+        assert (a - b).abs().max().item() <= 1e-4, f"guidance with identical branches changed the sample by {(a - b).abs().max():.3e}"
+        assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0 + 1e-6
+    with torch.no_grad():
+        e = model(torch.zeros((0, 3, 32, 32), device=DEV), torch.zeros((0,), dtype=torch.float64, device=DEV), torch.zeros((0,), device=DEV))
+    assert e.shape == (0, 3, 32, 32)

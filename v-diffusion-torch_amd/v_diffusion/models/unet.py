@@ -173,6 +173,8 @@ class UNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("v_diffusion.UNet runs on an MI355X through libvdiff_hip.so only; there is no CPU path "
                                "(the CPU restatement lives under oracle/ and is test infrastructure)")
+        if x.shape[0] == 0:                                   # empty batch: nothing to launch (F.conv2d returns an empty tensor too)
+            return x.new_zeros((0, self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32)
         params = list(self.parameters())
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             return _UNetFn.apply(self, x, t, y, *params)
