@@ -60,6 +60,7 @@ typedef struct vd_gemm_desc {
     float*  stats;              /* optional, forward launches: GroupNorm partials of the OUTPUT rows, laid out  */
     int32_t stats_hw;           /*   [image][chunk][2][N] with chunk = BM/2 rows (BM from vd_gemm_last_tile);    */
                                 /*   stats_hw = rows (pixels) per image; finalize: vd_gn_stats_from_partials     */
+    int64_t sBias;              /* batched launches: bias of entry z is bias + (z / nh) * sBias (0 = one shared bias) */
 } vd_gemm_desc;
 
 /* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two

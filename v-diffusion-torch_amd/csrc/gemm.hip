@@ -36,6 +36,7 @@ struct GemmArgs {
     float* colsum; int colsum_accumulate;     // COL-kind A only: colsum[m] (+)= sum_k A[k][m]  (bias gradients ride along)
     int probe;                                // timing experiments only (VD_GEMM_PROBE): bit0/bit1 drop the A/B tile loads
     float* stats; int stats_hw;               // GroupNorm partials of the OUTPUT: [img][chunk][2][N], chunk = BM/2 output rows
+    long long sBias;                          // bias offset per batch entry zb
 };
 
 __device__ __forceinline__ int row_swz(int row, int chunk) { return row * KT + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const float* B = p.B;
     float* C = p.C;
     const float* R = p.R;
+    const float* biasp = p.bias;
     int kt_begin = 0, kt_end = p.kt_total;
     if (SPLITK) {
         kt_begin = blockIdx.z * p.kt_per_split;
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         B += zb * p.sBb + zh * p.sBh;
         C += zb * p.sCb + zh * p.sCh;
         if (R) R += zb * p.sRb + zh * p.sRh;
+        if (biasp) biasp += zb * p.sBias;
     }
 
     // ---- per-thread staging coordinates
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const int n = n0 + ncol;
         const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
         if (!nok) continue;
-        const float bv = (!SPLITK && p.bias) ? p.bias[n] : 0.f;
+        const float bv = (!SPLITK && biasp) ? biasp[n] : 0.f;
         float st1 = 0.f, st2 = 0.f;           // per-column sum / sum of squares of this wave's BM/2 output rows
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     const float* B = p.B;
     float* C = p.C;
     const float* R = p.R;
+    const float* biasp = p.bias;
     int kt_begin = 0, kt_end = p.kt_total;
     if (SPLITK) {
         kt_begin = tbz * p.kt_per_split;
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         B += zb * p.sBb + zh * p.sBh;
         C += zb * p.sCb + zh * p.sCh;
         if (R) R += zb * p.sRb + zh * p.sRh;
+        if (biasp) biasp += zb * p.sBias;
     }
 
     // ---- constant per-thread source offsets (bytes) of every piece this thread takes part in
@@ -665,20 +670,32 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         const int n = n0 + ncol;
         const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
         if (!nok) continue;
-        const float bv = (!SPLITK && p.bias) ? p.bias[n] : 0.f;
+        const float bv = (!SPLITK && biasp) ? biasp[n] : 0.f;
         float st1 = 0.f, st2 = 0.f;           // per-column sum / sum of squares of this wave's BM/2 output rows
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
+            // residual / accumulate operands of the whole 32x32 block are fetched BEFORE its first store: C may alias R
+            // (and is its own input when accumulating), so the compiler must otherwise serialise 16 load->store round trips
+            float addv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rt = (r & 3) + 8 * (r >> 2) + 4 * lh;              // row inside the 32x32 MFMA block
                 const int m = m0 + wm + (A2 ? 2 * rt + a : 32 * a + rt);
+                float t = 0.f;
+                if (!SPLITK && m < p.M) {
+                    if (R) t = R[(long long)m * p.ldr + n];
+                    if (p.accumulate) t += C[(long long)m * p.ldc + n];
+                }
+                addv[r] = t;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rt = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + wm + (A2 ? 2 * rt + a : 32 * a + rt);
                 if (m >= p.M) continue;
                 float v = acc[a][b][r];
                 if (!SPLITK) {
-                    v = v * p.alpha + bv;
-                    if (R) v += R[(long long)m * p.ldr + n];
-                    if (p.accumulate) v += C[(long long)m * p.ldc + n];
+                    v = (v * p.alpha + bv) + addv[r];
                     st1 += v; st2 += v * v;
                 }
                 C[(long long)m * p.ldc + n] = v;
@@ -809,8 +826,10 @@ template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     g_last_tile = ((use_dma(a) ? ((BM == 128 && BN == 128 && ktile == 16) ? 16 : 32) : 0) * 1000 + BM) * 1000 + BN;
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
-    else if (BM == 128 && BN == 128 && ktile == 16)
-        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, ((BM == 128 && BN == 128) ? 16 : 32)>), grid, dim3(256), 0, st, a);
+    else if (BM == 128 && BN == 128 && ktile == 16) {
+        static const int pad = getenv("VD_GEMM_LDSPAD") ? atoi(getenv("VD_GEMM_LDSPAD")) : 0;   // experiments: caps workgroups/CU
+        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, ((BM == 128 && BN == 128) ? 16 : 32)>), grid, dim3(256), pad, st, a);
+    }
     else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32>), grid, dim3(256), 0, st, a);
 }
 
@@ -858,6 +877,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.kt_total = 0; a.kt_per_split = 0; a.slab_stride = 0;
     a.colsum = d.colsum; a.colsum_accumulate = d.colsum_accumulate;
     a.stats = d.stats; a.stats_hw = d.stats_hw;
+    a.sBias = d.sBias;
     { static const char* e = getenv("VD_GEMM_PROBE"); a.probe = e ? atoi(e) : 0; }
     VD_REQUIRE(!(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
 

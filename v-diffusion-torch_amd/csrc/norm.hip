@@ -129,27 +129,36 @@ __global__ void gn_stats_finalize_kernel(const float* part, int nimg, int chunks
 
 // statistics from the partials that producer GEMM epilogues left behind (vd_gemm / vd_conv3x3 `stats`): the normalised
 // tensor is the channel concatenation of up to two produced tensors, each with its own chunk size
-__global__ void gn_stats_from_partials_kernel(const float* p1, int C1, int ch1, const float* p2, int C2, int ch2, int nimg,
-                                              int G, long long HW, float eps, float* stats) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void gn_stats_from_partials_kernel(const float* p1, int C1, int ch1, const float* p2, int C2,
+                                                                     int ch2, int nimg, int G, long long HW, float eps,
+                                                                     float* stats) {
+    // one wave per (image, group): lanes stride over the group's (chunk, channel) partials, fixed-order butterfly in fp64
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= nimg * G) return;
     const int b = idx / G, g = idx % G, C = C1 + C2, cg = C / G;
     double s1 = 0.0, s2 = 0.0;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+    const int cbeg = g * cg;
+    // a group never straddles the two sources unless C1 is not a multiple of cg: handle the general case per channel
+    const int n1 = ch1 * cg, n2 = ch2 * cg;
+    for (int e = lane; e < max(n1, n2); e += 64) {
+        const int c = cbeg + e % cg, ch = e / cg;
         const bool first = c < C1;
-        const float* pp = first ? p1 : p2;
         const int Cs = first ? C1 : C2, cs = first ? c : c - C1, chunks = first ? ch1 : ch2;
-        for (int ch = 0; ch < chunks; ++ch) {
-            const float* q = pp + ((long long)(b * chunks + ch) * 2) * Cs + cs;
+        if (ch < chunks) {
+            const float* q = (first ? p1 : p2) + ((long long)(b * chunks + ch) * 2) * Cs + cs;
             s1 += (double)q[0]; s2 += (double)q[Cs];
         }
     }
-    const double n = (double)cg * (double)HW;
-    const double mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * idx] = (float)mean;
-    stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) {
+        const double n = (double)cg * (double)HW;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * idx] = (float)mean;
+        stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // coef[b][0][c] = rstd*gamma*(1+scale)   coef[b][1][c] = (beta - mean*rstd*gamma)*(1+scale) + shift
@@ -391,7 +400,7 @@ extern "C" int vd_gn_stats_from_partials(const float* part1, int32_t C1, int32_t
                                          void* stream) {
     VD_REQUIRE(part1 && C1 > 0 && chunks1 > 0 && (C1 + C2) % G == 0, "vd_gn_stats_from_partials: bad arguments");
     VD_REQUIRE(C2 == 0 || (part2 && chunks2 > 0), "vd_gn_stats_from_partials: second source incomplete");
-    hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3((nimg * G + 127) / 128), dim3(128), 0, (hipStream_t)stream, part1, C1,
+    hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3((nimg * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, part1, C1,
                        chunks1, part2, C2, chunks2, nimg, G, (long long)HW, eps, stats);
     VD_LAUNCH_CHECK("gn_stats_from_partials_kernel");
     return 0;

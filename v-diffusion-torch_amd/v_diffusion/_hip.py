@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("sCb", _i64), ("sCh", _i64), ("sRb", _i64), ("sRh", _i64),
                 ("alpha", _f32), ("accumulate", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32),
                 ("splitk", _i32), ("ws", _vp), ("ws_bytes", _i64), ("tile", _i32),
-                ("colsum", _vp), ("colsum_accumulate", _i32), ("stats", _vp), ("stats_hw", _i32)]
+                ("colsum", _vp), ("colsum_accumulate", _i32), ("stats", _vp), ("stats_hw", _i32), ("sBias", _i64)]
 
 
 _SIGNATURES = {
@@ -158,7 +158,7 @@ def workspace(nbytes, device, tag="default"):
 # ----------------------------------------------------------------------------------------------- wrappers
 def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None, R=None, ldr=0, batch=1, nh=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), alpha=1.0, accumulate=False, splitk=1, tile=0, colsum=None,
-         colsum_accumulate=False, stats=None, stats_hw=0):
+         colsum_accumulate=False, stats=None, stats_hw=0, sBias=0):
     d = GemmDesc()
     d.A, d.B, d.C, d.bias, d.R = ptr(A), ptr(B), ptr(Cm), ptr(bias), ptr(R)
     d.M, d.N, d.K, d.a_kind, d.b_kind = M, N, K, a_kind, b_kind
@@ -169,6 +169,7 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     d.splitk, d.tile = splitk, tile
     d.colsum, d.colsum_accumulate = ptr(colsum), int(colsum_accumulate)
     d.stats, d.stats_hw = ptr(stats), stats_hw
+    d.sBias = sBias
     if splitk > 1:
         ws = workspace(splitk * (M * N + M) * 4, A.device, "splitk")
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4

@@ -117,6 +117,16 @@ class UNetEngine:
                 nxt = plan[bi + 1] if bi + 1 < len(plan) else None
                 b.dest = ("cat", bi + 1, 0, b.cout) if (nxt is not None and nxt.consumes) else ("plain",)
         self.levels = levels
+        # FiLM projections (reference unet.py:129,143: one Linear per residual block, all fed by the SAME activated
+        # embedding): blocks with equal width are run as ONE batched GEMM per pass instead of a launch-latency-bound
+        # M = batch GEMM per block.  film_slot: residual-block prefix -> (2*Cout, index inside its group)
+        self.film_groups, self.film_slot = {}, {}
+        for b in plan:
+            if b.res is not None:
+                pre = b.prefix + (".0" if b.att is not None else "")
+                grp = self.film_groups.setdefault(2 * b.cout, [])
+                self.film_slot[pre] = (2 * b.cout, len(grp))
+                grp.append(b.res)
         # forward weight packs kept across calls while a sampler holds the weights fixed (set to {} by the sampling loop,
         # None otherwise: training repacks every step because the optimizer rewrites the weights)
         self.pack_cache = None
@@ -236,8 +246,42 @@ class UNetEngine:
         H.silu_bwd(h0, da0, dh0)
         self._linear_bwd(te0, l0.weight, dh0, G["time_embed.0.weight"], G["time_embed.0.bias"], None)
 
+    # ------------------------------------------------------------------------------------------ FiLM projections
+    def _film_fwd(self, ta, tape):
+        """film[g][i] = fc_i(ta) for every residual block i of width group g: [nb][B][2*Cout], one launch per group"""
+        B, E = ta.shape
+        films, stacks = {}, {}
+        cache = self.pack_cache
+        for c2, mods in self.film_groups.items():
+            key = ("film", c2)
+            if cache is not None and key in cache:
+                W, bv = cache[key]
+            else:
+                W = torch.stack([mm.fc.weight.detach() for mm in mods])          # [nb][2C][E]
+                bv = torch.stack([mm.fc.bias.detach() for mm in mods])           # [nb][2C]
+                if cache is not None:
+                    cache[key] = (W, bv)
+            nb = len(mods)
+            out = self._new(ta, nb, B, c2)
+            H.gemm(ta, W, out, B, c2, E, a_kind=H.ROW, b_kind=H.ROW, lda=E, ldb=E, ldc=c2, bias=bv, sBias=c2, batch=nb,
+                   sA=(0, 0), sB=(c2 * E, 0), sC=(B * c2, 0))
+            films[c2], stacks[c2] = out, W
+        if tape is not None:
+            tape["film_w"] = stacks
+        return films
+
+    def _film_bwd(self, dfilms, stacks, dta):
+        """dta += sum_i dfilm_i @ W_i : one batched GEMM per width group into per-block partials + one column sum"""
+        B, E = dta.shape
+        for c2, df in dfilms.items():
+            nb, W = df.shape[0], stacks[c2]
+            P = self._new(dta, nb, B * E)
+            H.gemm(df, W, P, B, E, c2, a_kind=H.ROW, b_kind=H.COL, lda=c2, ldb=E, ldc=E, batch=nb, sA=(B * c2, 0), sB=(c2 * E, 0),
+                   sC=(B * E, 0))
+            H.colsum(P, B * E, nb, B * E, dta.view(-1), accumulate=True)
+
     # ------------------------------------------------------------------------------------------ residual block
-    def _res_fwd(self, blk, mod, prefix, x, ta, dest, p_drop, seed, tape, x_parts=None):
+    def _res_fwd(self, blk, mod, prefix, x, films, dest, p_drop, seed, tape, x_parts=None):
         B, Hh, Ww, Cin, ldx = _chk(x)
         Cout, rs = blk.cout, blk.rs
         Ho, Wo = (Hh // 2, Ww // 2) if rs == H.RS_DOWN else ((Hh * 2, Ww * 2) if rs == H.RS_UP else (Hh, Ww))
@@ -249,8 +293,8 @@ class UNetEngine:
         ph = self._part(x, B, Ho * Wo, Cout)
         H.conv3x3(a1, Cin, self._pack_f(mod.conv1.weight), mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout, stats_part=ph)
         h1_parts = self._parts(ph, Cout, Ho * Wo)
-        film = self._new(x, B, 2 * Cout)
-        self._linear(ta, mod.fc.weight, mod.fc.bias, film)
+        c2, fi = self.film_slot[prefix]
+        film = films[c2][fi]                              # [B][2*Cout], contiguous slice of the group's batched GEMM output
         stats2, coef2 = self._new(x, B, GROUPS, 2), self._new(x, B, 4, Cout)
         self._stats(h1, h1_parts, B, Ho * Wo, Cout, stats2)
         a2 = self._new(x, B, Ho, Wo, Cout)
@@ -274,10 +318,10 @@ class UNetEngine:
         out_parts = self._parts(pd, Cout, Ho * Wo)
         if tape is not None:
             tape[prefix] = dict(x=x, coef1=coef1, a1=a1, h1=h1, coef2=coef2, a2=a2, film=film, xs=xs if has_skip else None,
-                                seed=seed, p=p_drop, ta=ta)
+                                seed=seed, p=p_drop)
         return out_parts
 
-    def _res_bwd(self, blk, mod, prefix, ctx, dy, dx, dx_accumulate, dta, G):
+    def _res_bwd(self, blk, mod, prefix, ctx, dy, dx, dx_accumulate, ta, dfilms, G):
         x, a1, h1, a2, film = ctx["x"], ctx["a1"], ctx["h1"], ctx["a2"], ctx["film"]
         B, Hh, Ww, Cin, ldx = _chk(x)
         _, Ho, Wo, Cout, lddy = _chk(dy)
@@ -289,7 +333,8 @@ class UNetEngine:
         H.conv3x3(dy, lddy, self._pack_d(mod.conv2.weight), None, da2, Cout, B, Ho, Wo, Cout, Cout)
         # norm2 + FiLM + SiLU + dropout
         dh1 = self._new(x, B, Ho, Wo, Cout)
-        dfilm = self._new(x, B, 2 * Cout)
+        c2, fi = self.film_slot[prefix]
+        dfilm = dfilms[c2][fi]
         H.gn_apply_bwd(da2, Cout, h1, Cout, ctx["coef2"], mod.norm2.weight, mod.norm2.bias, film, 1, ctx["p"], ctx["seed"],
                        H.RS_NONE, None, 0, dh1, Cout, False, dfilm, G[prefix + ".norm2.weight"], G[prefix + ".norm2.bias"], False,
                        B, Ho, Wo, Cout, GROUPS)
@@ -321,9 +366,9 @@ class UNetEngine:
         H.gn_apply_bwd(da1, Cin, x, ldx, ctx["coef1"], mod.norm1.weight, mod.norm1.bias, None, 1, 0.0, 0, rs, addt, _ld(addt),
                        dx, _ld(dx), dx_accumulate, None, G[prefix + ".norm1.weight"], G[prefix + ".norm1.bias"], False,
                        B, Hh, Ww, Cin, GROUPS)
-        # FiLM projection: film = fc(ta)
-        ta = ctx["ta"]
-        self._linear_bwd(ta, mod.fc.weight, dfilm, G[prefix + ".fc.weight"], G[prefix + ".fc.bias"], dta, dx_accumulate=True)
+        # FiLM projection film = fc(ta): weight/bias gradient here (keeps the gradient-completion order); the embedding
+        # gradient of all blocks is one batched GEMM at the end of backward (_film_bwd)
+        self._linear_bwd(ta, mod.fc.weight, dfilm, G[prefix + ".fc.weight"], G[prefix + ".fc.bias"], None)
 
     # ------------------------------------------------------------------------------------------ attention block
     def _attn_fwd(self, mod, prefix, x, dest, tape, x_parts=None):
@@ -403,6 +448,7 @@ class UNetEngine:
         tape = {} if save else None
         x_nchw = x_nchw.to(torch.float32).contiguous()
         ta = self._embed_fwd(t, y, tape)
+        films = self._film_fwd(ta, tape)
         p_drop = float(m.drop_rate) if training else 0.0
         base_seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p_drop > 0 else 0
         cip = (Ci + 3) // 4 * 4
@@ -448,10 +494,10 @@ class UNetEngine:
                 out_parts = self._attn_fwd(b.att, b.prefix, inp, out, tape, inp_parts)
             elif b.att is not None:
                 mid = self._new(x_nchw, B, oh, ow, b.cout)
-                mid_parts = self._res_fwd(b, b.res, b.prefix + ".0", inp, ta, mid, p_drop, base_seed + 2 * bi + 1, tape, inp_parts)
+                mid_parts = self._res_fwd(b, b.res, b.prefix + ".0", inp, films, mid, p_drop, base_seed + 2 * bi + 1, tape, inp_parts)
                 out_parts = self._attn_fwd(b.att, b.prefix + ".1", mid, out, tape, mid_parts)
             else:
-                out_parts = self._res_fwd(b, b.res, b.prefix, inp, ta, out, p_drop, base_seed + 2 * bi + 1, tape, inp_parts)
+                out_parts = self._res_fwd(b, b.res, b.prefix, inp, films, out, p_drop, base_seed + 2 * bi + 1, tape, inp_parts)
             if spec[0] == "cat":
                 cat_parts.setdefault(spec[1], {})[spec[2]] = out_parts
             if b.kind == "down":
@@ -487,6 +533,7 @@ class UNetEngine:
         B, H0, W0, cop, _ = _chk(dout)
         ta = tape["ta"]
         dta = torch.zeros_like(ta)
+        dfilms = {c2: self._new(ta, len(mods), B, c2) for c2, mods in self.film_groups.items()}
         # ---- out_conv
         C0 = m.hid_channels * m.ch_multipliers[0]
         gn, conv = m.out_conv[0], m.out_conv[2]
@@ -523,10 +570,10 @@ class UNetEngine:
             elif b.att is not None:
                 dmid = self._new(dout, *tape[b.prefix + ".1"]["x"].shape)
                 self._attn_bwd(b.att, b.prefix + ".1", tape[b.prefix + ".1"], dy, dmid, False, G)
-                self._res_bwd(b, b.res, b.prefix + ".0", tape[b.prefix + ".0"], dmid, dxbuf, acc, dta, G)
+                self._res_bwd(b, b.res, b.prefix + ".0", tape[b.prefix + ".0"], dmid, dxbuf, acc, ta, dfilms, G)
                 del dmid
             else:
-                self._res_bwd(b, b.res, b.prefix, tape[b.prefix], dy, dxbuf, acc, dta, G)
+                self._res_bwd(b, b.res, b.prefix, tape[b.prefix], dy, dxbuf, acc, ta, dfilms, G)
             progress(b.prefix + ".norm.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
             if b.kind == "up" and b.consumes:
                 dh_cur = dxbuf[..., :b.ch_h]
@@ -550,6 +597,7 @@ class UNetEngine:
                       m.in_channels)
             dx = self._new(dout, B, m.in_channels, H0, W0)
             H.nhwc_to_nchw(d4, cip, dx, B, m.in_channels, H0, W0)
+        self._film_bwd(dfilms, tape["film_w"], dta)
         self._embed_bwd(tape["embed"], dta, G)
         progress(None)
         return dx
