@@ -173,7 +173,8 @@ def test_conv3x3_dgrad(H, case):
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 32, 64, 32, 64), (4, 16, 16, 64, 32, 64, 32), (4, 32, 32, 192, 192, 192, 192),
                                   (2, 16, 16, 576, 192, 576, 192), (2, 16, 16, 192, 384, 192, 384), (2, 32, 32, 256, 256, 256, 256),
-                                  (3, 16, 16, 4, 32, 3, 32), (3, 8, 8, 32, 4, 32, 3), (8, 32, 32, 32, 32, 32, 32)])
+                                  (3, 16, 16, 4, 32, 3, 32), (3, 8, 8, 32, 4, 32, 3), (8, 32, 32, 32, 32, 32, 32),
+                                  (64, 32, 32, 128, 128, 128, 128)])    # last: >= 64 Ki pixels -> KT = 16 split-K kernel
 def test_conv3x3_wgrad(H, case):
     nimg, Hh, Ww, Cin, Cout, Cin_w, Cout_w = case
     x = torch.zeros(nimg, Cin, Hh, Ww)

@@ -813,23 +813,28 @@ int choose_tile(long long M, long long Ncols, bool wgrad, long long zcount, int 
 }
 
 // K tile of the kernel that will run.  The 128x128 LDS-DMA kernel exists with KT = 32 (64 KB LDS, 2 workgroups per CU)
-// and KT = 16 (32 KB, 5 per CU): the deeper occupancy wins (+2-3 %) only when the launch has enough workgroups to
-// give every CU five of them; short launches and the split-K weight gradient keep the longer K tile.
-inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk) {
+// and KT = 16 (32 KB LDS, ~106 VGPRs: 4 per CU): the deeper occupancy wins (+2-3 %) only when the launch has enough
+// workgroups to give every CU four of them for a long time; short launches keep the longer K tile.  `wide` = the caller
+// (conv weight gradient with >= 64 Ki pixels) sized its split-K slabs for 4 workgroups per CU.
+inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk, bool wide) {
     static const char* force = getenv("VD_GEMM_KT");
     if (t != 0 || !use_dma(a)) return KT;
     if (force) return atoi(force) == 16 ? 16 : 32;
-    return (!splitk && nblocks >= 2048) ? 16 : 32;
+    if (splitk) return wide ? 16 : 32;
+    return nblocks >= 2048 ? 16 : 32;
 }
+
+// conv weight gradients with at least this many pixels (K of the GEMM) run the KT = 16 kernel, 4 workgroups per CU
+// (measured: +2-3 % at 128 Ki pixels, -0..20 % at 32 Ki and below)
+constexpr long long WGRAD_WIDE_PIXELS = 65536;
 
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
-    g_last_tile = ((use_dma(a) ? ((BM == 128 && BN == 128 && ktile == 16) ? 16 : 32) : 0) * 1000 + BM) * 1000 + BN;
+    constexpr bool has16 = BM == 128 && BN == 128;       // the only tile with a KT = 16 instantiation
+    const bool k16 = has16 && ktile == 16;
+    g_last_tile = ((use_dma(a) ? (k16 ? 16 : 32) : 0) * 1000 + BM) * 1000 + BN;
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
-    else if (BM == 128 && BN == 128 && ktile == 16) {
-        static const int pad = getenv("VD_GEMM_LDSPAD") ? atoi(getenv("VD_GEMM_LDSPAD")) : 0;   // experiments: caps workgroups/CU
-        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, ((BM == 128 && BN == 128) ? 16 : 32)>), grid, dim3(256), pad, st, a);
-    }
+    else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32)>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32>), grid, dim3(256), 0, st, a);
 }
 
@@ -891,7 +896,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
         VD_REQUIRE(d.stats_hw > 0 && d.stats_hw % (tbm / 2) == 0 && d.M % d.stats_hw == 0,
                    "vd_gemm: output statistics need H*W (%d) to be a multiple of half the row tile (%d)", d.stats_hw, tbm / 2);
     }
-    const int ktile = ktile_for(a, tile, nm * nn * batch, splitk > 1);
+    const int ktile = ktile_for(a, tile, nm * nn * batch, splitk > 1, wgrad && (long long)d.K >= WGRAD_WIDE_PIXELS);
     a.kt_total = conv ? 9 * ((d.Cin + ktile - 1) / ktile) : (d.K + ktile - 1) / ktile;
     a.kt_per_split = a.kt_total;
 
@@ -965,7 +970,8 @@ static void wgrad_plan(int nimg, int H, int W, int Cin, int Cout, int* tile_out,
     const int t = choose_tile(Cout, Cin, true, 64, 0);   // the slab count below fills the chip whatever the tile
     const long long kt = ((long long)nimg * H * W + 31) / 32;
     const long long tiles = ((Cout + TILES[t].bm - 1) / TILES[t].bm) * 9LL * ((Cin + TILES[t].bn - 1) / TILES[t].bn);
-    const long long slots = 256LL * TILES[t].per_cu;
+    const bool wide = t == 0 && (long long)nimg * H * W >= WGRAD_WIDE_PIXELS;
+    const long long slots = 256LL * (wide ? 4 : TILES[t].per_cu);
     int best = 1;
     double best_eff = 0.0;
     for (int s = 1; s <= 64; ++s) {
