@@ -294,6 +294,74 @@ def test_hot_path_trainer_matches_torch_optimizer(vd):
     assert list(sd.keys()) == list(ref.state_dict().keys())
 
 
+def test_checkpoint_interchange_and_ema_swap(vd, tmp_path):
+    """train_utils.py:309-348 / utils.py:131-193: a checkpoint written by HotPathTrainer is consumable by the reference's
+    loaders (torch AdamW / LambdaLR load_state_dict, EMA dict), one written in the reference's format resumes the
+    flat-buffer trainer bit-exactly, and the EMA context runs the model on the shadow weights without copying."""
+    import copy
+    from oracle.cases import TINY, make_inputs
+    from v_diffusion.trainer import HotPathTrainer
+    case = TINY["tinyC"]
+    cfg = case["cfg"]
+    gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine"), 8, "v", "fixed_large", "snr_trunc", "mse", p_uncond=0.0)
+    x, _, _ = make_inputs(cfg, 4, case["R"], case["label"], seed=5)
+    x = x.clamp(-1, 1).to(DEV)
+    kw = dict(lr=1e-3, weight_decay=0.01, warmup=4, grad_norm=0.5, ema_decay=0.9, use_ema=True)
+    m1, _ = _build(vd, cfg, train=True)
+    t1 = HotPathTrainer(m1, gd, **kw)
+    for _ in range(3):
+        t1.step(x, None)
+    path = str(tmp_path / "ckpt.pt")
+    t1.save_checkpoint(path, epoch=3)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) >= {"model", "optimizer", "ema", "scheduler", "rng", "epoch"}
+    # (a) the reference's consumers accept it: torch.optim.AdamW / LambdaLR / UNet.load_state_dict
+    ref = vd.UNet(**cfg)
+    ref.load_state_dict(ck["model"])
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda t: min((t + 1) / 4, 1.0))
+    opt.load_state_dict(ck["optimizer"])
+    sched.load_state_dict(ck["scheduler"])
+    assert sched.last_epoch == 3 and abs(opt.param_groups[0]["lr"] - 1e-3 * 3 / 4) < 1e-12
+    names = [k for k, _ in ref.named_parameters()]
+    assert set(ck["ema"]["shadow"]) == set(names) and ck["ema"]["num_updates"] == 3
+    for i, p in enumerate(ref.parameters()):
+        assert float(opt.state[p]["step"]) == 3.0 and opt.state[p]["exp_avg"].shape == p.shape
+    # (b) resume: a fresh trainer loaded from the file continues exactly like the one that kept running
+    m2, _ = _build(vd, cfg, train=True)
+    t2 = HotPathTrainer(m2, gd, **kw)
+    assert t2.load_checkpoint(path) == 3
+    l1, l2 = t1.step(x, None), t2.step(x, None)
+    assert float(l1) == float(l2)
+    assert torch.equal(t1.flat.p, t2.flat.p) and torch.equal(t1.flat.ema, t2.flat.ema) and torch.equal(t1.flat.m, t2.flat.m)
+    # (c) a checkpoint in the reference's own format (torch optimizer state, DDP "module." prefixes on the shadow)
+    ck_ref = {"model": {"module." + k: v for k, v in ref.state_dict().items()}, "optimizer": opt.state_dict(),
+              "scheduler": sched.state_dict(), "epoch": 7,
+              "ema": {"decay": 0.9, "num_updates": 3, "shadow": {k: v.clone() for k, v in ck["ema"]["shadow"].items()}}}
+    m3, _ = _build(vd, cfg, train=True)
+    t3 = HotPathTrainer(m3, gd, **kw)
+    assert t3.load_checkpoint(ck_ref) == 7
+    assert t3.flat.step_count == 3 and t3.flat.ema_updates == 3
+    for k, p in m3.named_parameters():
+        assert torch.equal(p.detach().cpu(), ck["model"][k])
+    sd3 = t3.state_dicts()
+    for i, k in enumerate(names):
+        assert torch.equal(sd3["optimizer"]["state"][i]["exp_avg_sq"].cpu(), ck["optimizer"]["state"][i]["exp_avg_sq"])
+    # (d) EMA context: forward on the shadow weights, raw weights back afterwards, nothing copied
+    xt, tt, _ = make_inputs(cfg, 2, case["R"], case["label"], seed=9)
+    m1.eval()
+    before = m1(xt.to(DEV), tt.to(DEV))
+    ptrs = [p.data_ptr() for p in m1.parameters()]
+    with t1.ema_weights():
+        with_ema = m1(xt.to(DEV), tt.to(DEV))
+        ema_model = vd.UNet(**cfg)
+        ema_model.load_state_dict({k: v.cpu() for k, v in t1.flat.ema_state_dict().items()})
+        ema_model.to(DEV).eval()
+        assert torch.equal(with_ema, ema_model(xt.to(DEV), tt.to(DEV)))
+    assert [p.data_ptr() for p in m1.parameters()] == ptrs
+    assert torch.equal(m1(xt.to(DEV), tt.to(DEV)), before) and not torch.equal(before, with_ema)
+
+
 @pytest.mark.parametrize("B,Hh,Ww", [(1, 8, 16), (5, 16, 8), (2, 4, 4)])
 def test_ragged_batch_and_non_square_images(vd, B, Hh, Ww):
     """edge cases the reference handles implicitly: batch of one, odd batch, non-square images, 2x2 bottleneck"""

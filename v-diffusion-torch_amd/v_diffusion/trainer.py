@@ -193,3 +193,115 @@ class HotPathTrainer:
             _hip.adamw_ema(flat.p, flat.g, flat.m, flat.v, flat.ema, flat.gnorm_sq, float(self.grad_norm), lr, self.betas[0],
                            self.betas[1], self.eps, self.wd, 1 - self.betas[0] ** k, 1 - self.betas[1] ** k, decay)
         return loss.detach()
+
+    # ------------------------------------------------------------------ EMA weights for sampling (utils.py:151-166)
+    def ema_weights(self):
+        """``with trainer.ema_weights(): ...`` runs the body on the EMA shadow.  The reference clones every parameter
+        (``EMA.apply``) and copies back (``restore``); here the module's ``.data`` views are re-pointed from the flat
+        parameter buffer to the flat shadow buffer and back -- no device traffic at all."""
+        return _EmaSwap(self.flat)
+
+    # ------------------------------------------------------------------ checkpoints (train_utils.py:309-348)
+    def _lr_now(self):
+        k = self.flat.step_count
+        return self.lr * (min(k / self.warmup, 1.0) if self.warmup > 0 else 1.0)
+
+    def state_dicts(self):
+        """The reference's ``named_state_dicts`` payload: the same keys and per-entry formats ``Trainer.load_checkpoint``
+        feeds to ``UNet.load_state_dict`` / ``torch.optim.AdamW.load_state_dict`` / ``EMA.load_state_dict`` /
+        ``LambdaLR.load_state_dict`` (optimizer state indexed by position in ``model.parameters()``)."""
+        flat, names = self.flat, [k for k, _ in self.model.named_parameters()]
+        params = dict(self.model.named_parameters())
+
+        def view(buf, k):
+            return buf[flat.offsets[k]: flat.offsets[k] + params[k].numel()].view_as(params[k])
+
+        out = {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()}}
+        state = {}
+        if flat.step_count > 0:
+            for i, k in enumerate(names):
+                state[i] = {"step": torch.tensor(float(flat.step_count)), "exp_avg": view(flat.m, k).clone(),
+                            "exp_avg_sq": view(flat.v, k).clone()}
+        group = {"lr": self._lr_now(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "initial_lr": self.lr, "params": list(range(len(names)))}
+        out["optimizer"] = {"state": state, "param_groups": [group]}
+        if flat.ema is not None:
+            out["ema"] = {"decay": self.ema_decay, "shadow": {k: view(flat.ema, k).clone() for k in names},
+                          "num_updates": flat.ema_updates}
+        out["scheduler"] = {"base_lrs": [self.lr], "last_epoch": flat.step_count, "_step_count": flat.step_count + 1,
+                            "_get_lr_called_within_step": False, "_last_lr": [self._lr_now()], "lr_lambdas": [None]}
+        return out
+
+    def save_checkpoint(self, path, **extra):
+        ckpt = self.state_dicts()
+        ckpt["rng"] = {self.rank: self.generator.get_state()}
+        ckpt.update(extra)
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path_or_dict, map_location=None):
+        """Reads a checkpoint written by the reference ``Trainer.save_checkpoint`` (or by ``save_checkpoint`` above):
+        weights, Adam moments and step, EMA shadow and update count, LR-schedule position, per-rank generator state.
+        ``module.``-prefixed keys (saved from a DDP wrapper) are accepted as the reference does (:319-323)."""
+        ckpt = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location=map_location or "cpu")
+        flat, names = self.flat, [k for k, _ in self.model.named_parameters()]
+        params = dict(self.model.named_parameters())
+
+        def strip(d):
+            return {(k[7:] if k.startswith("module.") else k): v for k, v in d.items()}
+
+        def view(buf, k):
+            return buf[flat.offsets[k]: flat.offsets[k] + params[k].numel()].view_as(params[k])
+
+        self.model.load_state_dict(strip(ckpt["model"]))
+        with torch.no_grad():
+            opt = ckpt.get("optimizer")
+            if opt is not None:
+                st = opt["state"]
+                assert len(st) in (0, len(names)), "optimizer state does not match the parameter list"
+                flat.m.zero_(); flat.v.zero_()
+                steps = set()
+                for i, k in enumerate(names):
+                    e = st.get(i, st.get(str(i)))
+                    if e is None:
+                        continue
+                    view(flat.m, k).copy_(e["exp_avg"])
+                    view(flat.v, k).copy_(e["exp_avg_sq"])
+                    steps.add(int(e["step"]))
+                assert len(steps) <= 1, "per-parameter step counts differ"
+                flat.step_count = steps.pop() if steps else 0
+            ema = ckpt.get("ema")
+            if ema is not None and flat.ema is not None:
+                shadow = strip(ema["shadow"])
+                missing = set(names) ^ set(shadow)
+                if missing:
+                    raise RuntimeError(f"EMA key mismatch: {sorted(missing)[:4]} ...")
+                for k in names:
+                    view(flat.ema, k).copy_(shadow[k])
+                flat.ema_updates = int(ema["num_updates"])
+                self.ema_decay = float(ema.get("decay", self.ema_decay))
+            sch = ckpt.get("scheduler")
+            if sch is not None and opt is None:
+                flat.step_count = int(sch.get("last_epoch", flat.step_count))
+        if "rng" in ckpt and ckpt["rng"] is not None and int(self.rank) in ckpt["rng"]:
+            self.generator.set_state(ckpt["rng"][int(self.rank)].cpu())
+        return ckpt.get("epoch", 0)
+
+
+class _EmaSwap:
+    def __init__(self, flat):
+        self.flat = flat
+
+    def _point(self, buf):
+        flat = self.flat
+        for k, q in flat.model.named_parameters():
+            q.data = buf[flat.offsets[k]: flat.offsets[k] + q.numel()].view_as(q)
+
+    def __enter__(self):
+        assert self.flat.ema is not None, "trainer was built with use_ema=False"
+        self._point(self.flat.ema)
+        return self
+
+    def __exit__(self, *exc):
+        self._point(self.flat.p)
+        return False
