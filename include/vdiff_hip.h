@@ -178,6 +178,16 @@ int vd_loss_fwd(const float* x0, const float* eps, const float* xt, const float*
 int vd_loss_bwd(const float* x0, const float* eps, const float* xt, const float* out, const float* logsnr,
                 const float* aux, const float* gloss, int32_t model_out_type, int32_t reweight, float* dout,
                 int32_t n, int32_t C, int32_t HW, void* stream);
+/* variational-bound terms of one step (loss_type "kl": GaussianDiffusion._loss_term_bpd diffusion.py:446-464 with
+ * normal_kl / discretized_gaussian_loglik of functions.py:31-67), per sample and in bits per dimension:
+ *   kl[b]  = mean KL( q(x_s|x_t,x_0) || p(x_s|x_t) ) / ln 2 ,  nll[b] = mean -log p(x_0|x_t) / ln 2 (8-bit bins)
+ * coef[n][8] (device) = {a0, b0x, b0e, c1, c2, true_logvar, model_logvar, 0} per sample: x0_hat = clip?(a0*xt + b0x*out
+ * (+ b0e*out_eps)), true_mean = c1*xt + c2*x0, model_mean = c1*xt + c2*x0_hat.  pred (x0_hat, NCHW) and mse[n] are optional. */
+int vd_bpd_terms(const float* x0, const float* xt, const float* out, const float* coef, int32_t model_out_type, int32_t clip,
+                 float* kl, float* nll, float* pred, float* mse, int32_t n, int32_t C, int32_t HW, void* stream);
+/* dout = gloss[b] * d (use_kl[b] != 0 ? kl[b] : nll[b]) / d out   (autograd of the "kl" branch of train_loss, :497-515) */
+int vd_bpd_bwd(const float* x0, const float* xt, const float* out, const float* coef, const float* use_kl, const float* gloss,
+               int32_t model_out_type, int32_t clip, float* dout, int32_t n, int32_t C, int32_t HW, void* stream);
 /* one reverse step (p_mean_var + CFG + noise, diffusion.py:317-392) for a batch that shares the step index.
  * out has n*(1+cfg) images, cond/uncond interleaved when cfg (diffusion.py:369-372).
  * k: 8 HOST floats {a0, b0x, b0e, c1, c2, noise_scale, w_guide, 0}:  x0_hat = clip(a0*xt + b0x*out (+ b0e*out_eps)),

@@ -41,3 +41,17 @@ def make_inputs(cfg, B, R, label, seed=0):
 
 def make_weights(cfg, seed=0):
     return detrand.fill_state_dict(param_shapes(cfg), seed)
+
+
+def kl_case():
+    """inputs of the variational-bound fixtures (tests/golden/ext_kl.npz; oracle/make_goldens_ext.py builds the same tensors)"""
+    case = TINY["tinyA"]
+    cfg = case["cfg"]
+    x0, t, y = make_inputs(cfg, 6, case["R"], case["label"], seed=3)
+    x0 = (x0.clamp(-1, 1) * 127.5).round() / 127.5          # 8-bit data, as the discretised likelihood assumes
+    x0[0, :, :2] = 1.0                                       # both saturation branches of the decoder likelihood
+    x0[1, :, :2] = -1.0
+    t[0] = 0.05                                              # snaps to t = 1/T, s = 0: the decoder-NLL row
+    noise = detrand.normal("noise", tuple(x0.shape), 3)
+    out = detrand.normal("out", tuple(x0.shape), 4) * 0.5
+    return cfg, x0, t, y, noise, out

@@ -9,6 +9,8 @@ Restates, in plain torch on CPU:
   * prediction conversions ......... diffusion.py:206-245
   * train_loss (mse branch) ........ diffusion.py:492-545 (+ from_model_out_to_pred :466-490)
   * p_mean_var / p_sample_step / p_sample ... diffusion.py:317-414
+  * eps/x0 form of the posteriors (x0eps_coef=True) ... diffusion.py:137-140,180-182,195-197,338-347
+  * variational-bound terms (loss_type="kl") ... diffusion.py:446-464,497-515 + functions.py:31-63
 
 Schedule and posterior arithmetic is fp64 and cast to fp32 at the end, as in the reference.
 """
@@ -60,13 +62,18 @@ def log1mexp(x):
 
 
 # ----------------------------------------------------------------------------- posteriors
-def ddpm_coefs(logsnr_s, logsnr_t, var_type, intp_frac=None):
-    """E[x_s | x_t, x_0] = c1*x_t + c2*x_0 and the log-variance (diffusion.py:126-163, x0eps_coef=False)."""
+def ddpm_coefs(logsnr_s, logsnr_t, var_type, intp_frac=None, x0eps_coef=False):
+    """E[x_s | x_t, x_0] = c1*x_t + c2*x_0 and the log-variance (diffusion.py:126-163); with ``x0eps_coef`` the mean
+    is written c1*eps + c2*x_0 instead (:137-140)."""
     ls, lt = logsnr_s.to(F64), logsnr_t.to(F64)
     logr = lt - ls
     l1mr = log1mexp(logr)
-    c1 = torch.exp(logr + 0.5 * (F.logsigmoid(ls) - F.logsigmoid(lt)))
-    c2 = torch.exp(l1mr + 0.5 * F.logsigmoid(ls))
+    if x0eps_coef:
+        c1 = torch.exp(0.5 * (F.logsigmoid(ls) - lt) + logr)
+        c2 = torch.sigmoid(ls).sqrt()
+    else:
+        c1 = torch.exp(logr + 0.5 * (F.logsigmoid(ls) - F.logsigmoid(lt)))
+        c2 = torch.exp(l1mr + 0.5 * F.logsigmoid(ls))
     v_small = l1mr + F.logsigmoid(-ls)
     v_large = l1mr + F.logsigmoid(-lt)
     if var_type == "fixed_large":
@@ -80,12 +87,32 @@ def ddpm_coefs(logsnr_s, logsnr_t, var_type, intp_frac=None):
     return c1.float(), c2.float(), lv.float()
 
 
-def ddim_coefs(logsnr_s, logsnr_t):
-    """eta = 0 DDIM (diffusion.py:169-187): c1 = sigma_s/sigma_t, c2 = alpha_s (1 - sqrt(SNR_t/SNR_s)), logvar = -inf."""
+def ddim_coefs(logsnr_s, logsnr_t, x0eps_coef=False):
+    """eta = 0 DDIM (diffusion.py:169-187): c1 = sigma_s/sigma_t, c2 = alpha_s (1 - sqrt(SNR_t/SNR_s)), logvar = -inf.
+    With ``x0eps_coef`` the reference returns the LOGARITHMS of (sigma_s, alpha_s) -- it forgets the exp at :180-182 --
+    and that is what its sampler then multiplies with; restated as is."""
     ls, lt = logsnr_s.to(F64), logsnr_t.to(F64)
+    if x0eps_coef:
+        return (0.5 * F.logsigmoid(-ls)).float(), (0.5 * F.logsigmoid(ls)).float(), torch.tensor(-math.inf)
     c1 = torch.exp(0.5 * (F.logsigmoid(-ls) - F.logsigmoid(-lt)))
     c2 = torch.exp(log1mexp(0.5 * (lt - ls)) + 0.5 * F.logsigmoid(ls))
     return c1.float(), c2.float(), torch.tensor(-math.inf)
+
+
+def ddim_coefs_eta(logsnr_s, logsnr_t, eta, x0eps_coef=False):
+    """0 < eta < 1 (diffusion.py:188-203; eta = 1 is the fixed_small DDPM posterior, :173-174)."""
+    ls, lt = logsnr_s.to(F64), logsnr_t.to(F64)
+    logr = lt - ls
+    l1mr = log1mexp(logr)
+    lv = l1mr + F.logsigmoid(-ls) + 2 * math.log(eta)
+    w = log1mexp(2 * math.log(eta) + l1mr)
+    if x0eps_coef:
+        c1 = 0.5 * (w + F.logsigmoid(-ls))
+        c2 = 0.5 * F.logsigmoid(ls)
+    else:
+        c1 = 0.5 * (w + F.logsigmoid(-ls) - F.logsigmoid(-lt))
+        c2 = log1mexp(0.5 * (logr + w)) + 0.5 * F.logsigmoid(ls)
+    return c1.exp().float(), c2.exp().float(), lv.float()
 
 
 # ----------------------------------------------------------------------------- conversions
@@ -173,7 +200,7 @@ def train_loss(denoise_fn, schedule, x0, t, y, noise, model_out_type="v", reweig
 
 # ----------------------------------------------------------------------------- sampling
 def p_sample_step(denoise_fn, schedule, xt, step, T, y, noise, *, model_out_type="v", var_type="fixed_large",
-                  intp_frac=None, w_guide=0.0, use_ddim=False, clip=True):
+                  intp_frac=None, w_guide=0.0, use_ddim=False, clip=True, x0eps_coef=False):
     """One reverse step (diffusion.py:360-392).  ``step`` is a python int (identical for the batch);
     ``noise`` is the N(0,1) tensor the reference would draw at :389."""
     B = xt.shape[0]
@@ -193,11 +220,14 @@ def p_sample_step(denoise_fn, schedule, xt, step, T, y, noise, *, model_out_type
     px0 = predictions(model_out_type, x_in, out, lt2)[0]
     if clip:
         px0 = px0.clamp(-1.0, 1.0)
+    first = x_in
+    if x0eps_coef:                                  # the posterior is taken over (eps, x0) instead of (x_t, x0), :338-347
+        first = eps_from_x0(x_in, px0, lt2) if (clip or model_out_type != "eps") else out
     if use_ddim:
-        c1, c2, lv = ddim_coefs(ls2, lt2)
+        c1, c2, lv = ddim_coefs(ls2, lt2, x0eps_coef)
     else:
-        c1, c2, lv = ddpm_coefs(ls2, lt2, var_type, intp_frac)
-    mean = c1 * x_in + c2 * px0
+        c1, c2, lv = ddpm_coefs(ls2, lt2, var_type, intp_frac, x0eps_coef)
+    mean = c1 * first + c2 * px0
     if step == 0:
         mean = px0                                  # :378
     if cfg:
@@ -215,3 +245,56 @@ def p_sample(denoise_fn, schedule, x_T, T, y, noises, **kw):
     for step in reversed(range(T)):
         x = p_sample_step(denoise_fn, schedule, x, step, T, y, noises[step], **kw)
     return x
+
+
+# ----------------------------------------------------------------------------- variational bound (loss_type = "kl")
+def normal_kl(mean1, logvar1, mean2, logvar2):                                # functions.py:31-37
+    d = logvar1 - logvar2
+    return 0.5 * (-1.0 - d + (mean1 - mean2) ** 2 * torch.exp(-logvar2) + torch.exp(d))
+
+
+def approx_std_normal_cdf(x):                                                 # functions.py:40-47 (Page 1977)
+    return 0.5 * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def discretized_gaussian_loglik(x, means, log_scale, precision=1.0 / 255, cutoff=0.999, tol=1e-12):   # functions.py:50-67
+    xc = x - means
+    inv_std = torch.exp(-log_scale)
+    cdf_u = torch.where(x > cutoff, torch.ones((), dtype=torch.float32), approx_std_normal_cdf(inv_std * (xc + precision)))
+    cdf_l = torch.where(x < -cutoff, torch.zeros((), dtype=torch.float32), approx_std_normal_cdf(inv_std * (xc - precision)))
+    return torch.log(torch.clamp(cdf_u - cdf_l - tol, min=0) + tol)
+
+
+def loss_term_bpd(out, x0, xt, logsnr_s, logsnr_t, model_out_type="v", var_type="fixed_large", intp_frac=None, clip=False):
+    """(kl, decoder_nll, pred_x0) per sample, in bits per dimension (diffusion.py:446-464)."""
+    tc1, tc2, tlv = ddpm_coefs(logsnr_s, logsnr_t, "fixed_small")
+    true_mean = tc1 * xt + tc2 * x0
+    px0 = predictions(model_out_type, xt, out, logsnr_t)[0]
+    if clip:
+        px0 = px0.clamp(-1.0, 1.0)
+    c1, c2, lv = ddpm_coefs(logsnr_s, logsnr_t, var_type, intp_frac)
+    model_mean = c1 * xt + c2 * px0
+    kl = _fmean(normal_kl(true_mean, tlv, model_mean, lv)) / math.log(2.0)
+    nll = _fmean(-discretized_gaussian_loglik(x0, px0, 0.5 * lv)) / math.log(2.0)
+    return kl, nll, px0
+
+
+def train_loss_kl(denoise_fn, schedule, x0, t, y, noise, T, model_out_type="v", var_type="fixed_large", intp_frac=None):
+    """Per-sample un-weighted bound term (diffusion.py:497-515): t snapped up to the sampling grid, KL for s > 0,
+    decoder NLL for the last step."""
+    t = torch.ceil(t * T) / T
+    s = (t - 1.0 / T).clamp(min=0.0)
+    lt = _bcast(schedule(t), x0)
+    xt = q_sample(x0, lt, noise)
+    out = denoise_fn(xt, t, y)
+    ls = _bcast(schedule(s), x0)
+    kl, nll, _ = loss_term_bpd(out, x0, xt, ls, lt, model_out_type, var_type, intp_frac, clip=False)
+    return torch.where(s != 0, kl, nll)
+
+
+def prior_bpd(schedule, x0):
+    """KL(q(x_1 | x_0) || N(0, I)) in bits/dim -- what diffusion.py:547-553 is written to compute (the reference line
+    ``logsnr_t, = ...`` only unpacks for a batch of one; q_mean_var :249-250 and normal_kl are used as there)."""
+    lt = _bcast(schedule(torch.ones((x0.shape[0],), dtype=torch.float32)), x0)
+    mean, logvar = torch.sigmoid(lt).sqrt() * x0, F.logsigmoid(-lt)
+    return _fmean(normal_kl(mean, logvar, torch.zeros(()), torch.zeros(()))) / math.log(2.0)

@@ -1,6 +1,7 @@
 """CPU-side checks of the host package: C ABI export table, state_dict contract, engine plan, host schedule math.
 No compute kernels are launched here (there is no GPU in this tier)."""
 import ctypes
+import math
 import os
 import re
 
@@ -173,3 +174,85 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_host_posteriors_x0eps_and_eta_vs_golden(golden_dir):
+    """logsnr_to_posterior(_ddim) with x0eps_coef=True and 0 < eta < 1 against the reference's numbers"""
+    import v_diffusion
+    from v_diffusion.diffusion import logsnr_to_posterior, logsnr_to_posterior_ddim
+    g = np.load(os.path.join(golden_dir, "ext_tables.npz"))
+    f = v_diffusion.get_logsnr_schedule("cosine")
+    for T in (8, 50):
+        l = f(torch.arange(T + 1, dtype=torch.float64) / T)
+        ls, lt = l[:-1].float(), l[1:].float()
+        for vt, frac in (("fixed_large", None), ("fixed_small", None), ("fixed_medium", 0.3)):
+            c = logsnr_to_posterior(ls, lt, vt, frac, x0eps_coef=True)
+            np.testing.assert_allclose(np.stack([v.numpy() for v in c]), g[f"ddpm_x0eps_{vt}_{T}"], rtol=1e-6)
+        c = logsnr_to_posterior_ddim(ls, lt, 0.0, x0eps_coef=True)
+        np.testing.assert_allclose(np.stack([c[0].numpy(), c[1].numpy()]), g[f"ddim_x0eps_{T}"], rtol=1e-6)
+        for eta in (0.5, 0.2):
+            for xe in (False, True):
+                c = logsnr_to_posterior_ddim(ls, lt, eta, x0eps_coef=xe)
+                np.testing.assert_allclose(np.stack([v.numpy() for v in c]), g[f"ddim_eta{eta}_{'x0eps' if xe else 'xt'}_{T}"], rtol=1e-6)
+
+
+def test_reference_self_checks():
+    """The reference's own in-file checks (diffusion.py:583-676, run there as ``python diffusion.py``), on this build's
+    host functions: the eps/x0 and x_t/x0 forms of the posteriors agree, eta = 1 DDIM is the fixed_small posterior, the
+    "legacy" schedule reproduces the DDPM linear-beta alphas, and the cosine schedule inverts/round-trips."""
+    import v_diffusion
+    from v_diffusion.diffusion import logsnr_to_posterior, logsnr_to_posterior_ddim
+    sched = v_diffusion.get_logsnr_schedule("cosine")
+    logsnr = sched(torch.linspace(0, 1, 1001))
+    ls, lt = logsnr[:-1], logsnr[1:]
+    # test_logsnr_to_posterior (:583-591)
+    c1, c2, _ = logsnr_to_posterior(ls, lt, "fixed_small")
+    e1, e2, _ = logsnr_to_posterior(ls, lt, "fixed_small", x0eps_coef=True)
+    logr = lt - ls
+    assert torch.allclose(c1 * torch.sigmoid(-lt).sqrt(), e1)
+    assert torch.allclose(c2 + torch.sigmoid(ls).sqrt() * logr.exp(), e2)
+    # test_logsnr_to_posterior_ddim (:594-614)
+    for a, b in zip(logsnr_to_posterior(ls, lt, "fixed_small"), logsnr_to_posterior_ddim(ls, lt, eta=1.)):
+        assert torch.allclose(a, b)
+    c1, c2, _ = logsnr_to_posterior_ddim(ls, lt, eta=0.5)
+    e1, e2, _ = logsnr_to_posterior_ddim(ls, lt, eta=0.5, x0eps_coef=True)
+    assert torch.allclose(c1 * torch.sigmoid(-lt).sqrt(), e1)
+    # (the reference prints the second identity with alpha_s, :613, which is False there too; the consistent form uses alpha_t)
+    assert not torch.allclose(c2 + torch.sigmoid(ls).sqrt() * c1, e2)
+    assert torch.allclose(c2 + torch.sigmoid(lt).sqrt() * c1, e2)
+    # test_legacy (:617-624): continuous version of the linear-beta schedule
+    t = torch.linspace(0, 1, 1000, dtype=torch.float32)
+    alphas = torch.sigmoid(v_diffusion.get_logsnr_schedule("legacy")(t))
+    ref = torch.cumprod(1 - torch.linspace(0.0001, 0.02, 1000), dim=0)
+    # the reference prints 1.976e-3 / 3.794e-3 for these two errors (run here against /root/reference)
+    assert abs(float((alphas - ref).abs().max()) - 1.9765e-3) < 2e-6 and abs(float(((alphas - ref) / ref).abs().max()) - 3.7940e-3) < 2e-6
+    # test_schedule (:627-676): rescale=True rewrites t <- logsnr2t(logsnr) in place; cosine/sine/cotangent identities
+    f = v_diffusion.get_logsnr_schedule("cosine", rescale=True)
+    idx = np.linspace(0, 1000, 50).astype(np.int64)
+    t = torch.linspace(0, 1, 1001, dtype=torch.float32)[idx]
+    t_in = t.clone()
+    l = f(t)
+    at = torch.atan(l.clamp(-20, 20).mul(-0.5).exp()).div(0.5 * math.pi)
+    assert torch.allclose(t, at, atol=1e-6)
+    assert not torch.equal(t, t_in)                    # endpoints moved from [0, 1] to [t(logsnr_max), t(logsnr_min)]
+    li = l[1:-1]
+    assert torch.allclose(torch.sigmoid(li).sqrt(), li.exp().sqrt() * torch.sigmoid(-li).sqrt())
+    assert torch.allclose(torch.sigmoid(-li).sqrt(), li.neg().exp().sqrt() * torch.sigmoid(li).sqrt())
+    assert torch.allclose(li.mul(0.5).exp(), torch.sigmoid(li).sqrt() * torch.sigmoid(-li).rsqrt(), rtol=1e-4)
+
+
+def test_step_coefficients_fold_the_eps_form(golden_dir):
+    """x0eps_coef=True: the sampler's (x_t, x0_hat) weights reproduce c1*eps + c2*x0_hat with eps re-derived from x0_hat"""
+    import v_diffusion
+    g = np.load(os.path.join(golden_dir, "ext_tables.npz"))
+    T = 8
+    sched = v_diffusion.get_logsnr_schedule("cosine")
+    gd = v_diffusion.GaussianDiffusion(sched, T, "v", "fixed_medium", "snr_trunc", "mse", intp_frac=0.3, x0eps_coef=True)
+    l = sched(torch.arange(T + 1, dtype=torch.float64) / T).float().double()
+    for step in range(T):
+        k = gd._step_coefs(step, use_ddim=False)
+        c1, c2 = g["ddpm_x0eps_fixed_medium_8"][0, step].astype(np.float64), g["ddpm_x0eps_fixed_medium_8"][1, step].astype(np.float64)
+        alpha, sigma = float(torch.sigmoid(l[step + 1]).sqrt()), float(torch.sigmoid(-l[step + 1]).sqrt())
+        xt, x0h = 0.37, -0.81
+        want = c1 * (xt - alpha * x0h) / sigma + c2 * x0h
+        assert abs(k[3] * xt + k[4] * x0h - want) <= 1e-5 * max(1.0, abs(want))

@@ -481,6 +481,68 @@ def test_qsample_loss_fwd_bwd(H, mot, rw):
     close(dout, o64.grad, None, floor=2e-5, name="dloss")
 
 
+@pytest.mark.parametrize("mot,clip", [("v", False), ("v", True), ("both", False), ("eps", True), ("x0", False)])
+def test_bpd_terms_fwd_bwd(H, mot, clip):
+    """vd_bpd_terms / vd_bpd_bwd (KL and discretised decoder NLL, reference diffusion.py:446-464) against an fp64 autograd
+    evaluation of the oracle's expressions, at mid-chain variances where the tanh-CDF difference is well conditioned"""
+    import math as _m
+    from oracle import diffusion_ref as dref
+    n, Cc, R = 6, 3, 8
+    Co = 6 if mot == "both" else 3
+    x0 = ((rnd(n, Cc, R, R, seed=1).clamp(-1, 1) * 127.5).round() / 127.5)
+    x0[0, :, :2], x0[1, :, :2] = 1.0, -1.0
+    eps = rnd(n, Cc, R, R, seed=2)
+    sched = dref.make_schedule("cosine")
+    s = torch.tensor([0.3, 0.4, 0.5, 0.6, 0.7, 0.8], dtype=torch.float64)
+    ls, lt = sched(s).float().reshape(-1, 1, 1, 1), sched(s + 0.125).float().reshape(-1, 1, 1, 1)
+    xt = dref.q_sample(x0, lt, eps)
+    out = rnd(n, Co, R, R, seed=3) * 0.7
+
+    def terms(o, dt):
+        c1, c2, tlv = dref.ddpm_coefs(ls, lt, "fixed_small")
+        _, _, lv = dref.ddpm_coefs(ls, lt, "fixed_medium", 0.3)
+        c1, c2, tlv, lv = (v.to(dt) for v in (c1, c2, tlv, lv))
+        px0 = dref.predictions(mot, xt.to(dt), o, lt.to(dt))[0]
+        if clip:
+            px0 = px0.clamp(-1.0, 1.0)
+        kl = dref.normal_kl(c1 * xt.to(dt) + c2 * x0.to(dt), tlv, c1 * xt.to(dt) + c2 * px0, lv).flatten(1).mean(1) / _m.log(2.0)
+        xc, inv = x0.to(dt) - px0, torch.exp(-0.5 * lv)
+        cdf = lambda z: 0.5 * (1.0 + torch.tanh(_m.sqrt(2.0 / _m.pi) * (z + 0.044715 * z ** 3)))
+        cu = torch.where(x0 > 0.999, torch.ones((), dtype=dt), cdf(inv * (xc + 1.0 / 255)))
+        cl = torch.where(x0 < -0.999, torch.zeros((), dtype=dt), cdf(inv * (xc - 1.0 / 255)))
+        nll = (-torch.log(torch.clamp(cu - cl - 1e-12, min=0) + 1e-12)).flatten(1).mean(1) / _m.log(2.0)
+        return kl, nll, px0
+
+    o64 = out.double().requires_grad_(True)
+    kl64, nll64, p64 = terms(o64, torch.float64)
+    o32 = out.clone().requires_grad_(True)
+    kl32, nll32, _ = terms(o32, torch.float32)
+    use_kl = torch.tensor([1.0, 0.0, 1.0, 0.0, 1.0, 1.0])
+    gl = rnd(n, seed=4)
+    (torch.where(use_kl != 0, kl64, nll64) * gl.double()).sum().backward()
+    (torch.where(use_kl != 0, kl32, nll32) * gl).sum().backward()
+    kl32, nll32 = kl32.detach(), nll32.detach()
+    # coefficient table exactly as GaussianDiffusion._bpd_coefs builds it
+    import v_diffusion
+    gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine"), 8, mot, "fixed_medium", "snr_trunc", "kl", intp_frac=0.3)
+    coef = gd._bpd_coefs(ls.to(DEV), lt.to(DEV))
+    kl, nll, mse = (torch.empty(n, device=DEV) for _ in range(3))
+    pred = torch.empty(n, Cc, R, R, device=DEV)
+    H.bpd_terms(x0.to(DEV), xt.to(DEV), out.to(DEV), coef, H.OUT_TYPES[mot], clip, kl, nll, pred, mse, n, Cc, R * R)
+    close(kl, kl64.detach(), kl32, floor=2e-5, name="kl")
+    close(nll, nll64.detach(), nll32, floor=1e-4, name="nll")          # log of a difference of fp32 CDFs: ~4 digits
+    close(pred, p64.detach(), None, floor=2e-6, name="pred")
+    close(mse, ((p64.detach() - x0.double()) ** 2).flatten(1).mean(1), None, floor=1e-5, name="mse")
+    dout = torch.full((n, Co, R, R), 5.0, device=DEV)
+    H.bpd_bwd(x0.to(DEV), xt.to(DEV), out.to(DEV), coef, use_kl.to(DEV), gl.to(DEV), H.OUT_TYPES[mot], clip, dout, n, Cc, R * R)
+    rows = use_kl != 0
+    close(dout[rows.to(DEV)], o64.grad[rows], None, floor=2e-5, name="d kl")
+    # decoder-NLL rows: where a pixel's two fp32 tanh-CDFs saturate to the same number the clamp kills the gradient (in the
+    # reference's fp32 autograd too, not in fp64) -- compare with the fp32 autograd of the same expression, in L2
+    got, ref = dout[(~rows).to(DEV)].cpu().double(), o32.grad[~rows].double()
+    assert (got - ref).norm().item() <= 3e-2 * ref.norm().item(), "d nll"
+
+
 def test_sumsq_adamw_ema(H):
     n = 100003
     p, g = rnd(n, seed=1), rnd(n, seed=2) * 0.1

@@ -50,7 +50,7 @@ def _check_grads(g, model, rel=1e-4):
         nerr = abs(float(gr.norm()) - ref_norm)
         worst = max(worst, nerr / max(ref_norm, floor / rel))
         assert nerr <= rel * ref_norm + floor, f"{k}: |grad| {float(gr.norm()):.6e} vs reference {ref_norm:.6e}"
-        assert head_err <= 2e-4 * ref_norm + floor, f"{k}: leading elements differ by {head_err:.3e} (norm {ref_norm:.3e})"
+        assert head_err <= max(2e-4, rel) * ref_norm + floor, f"{k}: leading elements differ by {head_err:.3e} (norm {ref_norm:.3e})"
     return worst
 
 
@@ -248,6 +248,110 @@ def test_p_sample_trajectories_vs_golden(vd, golden_dir):
     assert float(preds.abs().max()) <= 3.0 + 1e-5                              # clipped x0 per branch, w=1: |c + (c - u)| <= 3
     _, p4 = gd.p_sample_progressive(model, shape, label=y, device=DEV, seed=11, use_ddim=True, pred_freq=4)
     assert p4.shape == (2, B, 3, R, R) and torch.equal(p4[0], preds[3]) and torch.equal(p4[1], preds[7])
+
+
+def test_p_sample_x0eps_form_vs_golden(vd, golden_dir):
+    """x0eps_coef=True (posterior over (eps, x0), reference :137-140,338-347) incl. the reference's log-valued DDIM weights"""
+    from oracle.cases import TINY
+    from oracle import detrand
+    g = _gold(golden_dir, "ext_p_sample.npz")
+    case = TINY["tinyA"]
+    model, _ = _build(vd, case["cfg"], train=False)
+    B, R, T = 3, case["R"], 8
+    shape = (B, 3, R, R)
+    x_T = detrand.normal("x_T", shape, 5)
+    y = torch.tensor([1.0, 7.0, 10.0])
+    noises = [detrand.normal(f"step{k}", shape, 5) for k in range(T)]
+    for tag, kw in (("ddpm_medium_cfg_x0eps", dict(use_ddim=False, w_guide=0.5, var_type="fixed_medium", intp_frac=0.3)),
+                    ("ddpm_large_nocfg_x0eps", dict(use_ddim=False, w_guide=0.0, var_type="fixed_large")),
+                    ("ddim_cfg_x0eps", dict(use_ddim=True, w_guide=1.0, var_type="fixed_large"))):
+        gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine", -20.0, 20.0), T, "v", kw["var_type"], "snr_trunc", "mse",
+                                  intp_frac=kw.get("intp_frac"), w_guide=kw["w_guide"], p_uncond=0.0, x0eps_coef=True)
+        order = iter(reversed(range(T)))
+
+        def fake_normal_(self, *a, **k):
+            return self.copy_(noises[next(order)])
+        with mock.patch.object(torch.Tensor, "normal_", fake_normal_):
+            x = gd.p_sample(model, shape, noise=x_T.clone(), label=y.clone(), device=DEV, seed=None, use_ddim=kw["use_ddim"])
+        err = np.abs(x.numpy() - g[tag]).max()
+        # the reference's log-valued DDIM weights (c1 down to -4.3 on x_t) make that chain expand perturbations: a 1e-6
+        # relative change of the network output moves ITS OWN end point by 9e-4 (measured with the oracle), against
+        # 4e-6 for the other chains -- so the whole chain is held to 1e-2 and every single step to 1e-4 below
+        tol = 1e-2 if tag == "ddim_cfg_x0eps" else 1e-4
+        assert err <= tol * max(1.0, float(np.abs(g[tag]).max())), f"{tag}: trajectory end differs by {err:.3e}"
+    # single reverse steps of the DDIM chain against the oracle on the same state
+    from oracle import diffusion_ref as dref, unet_ref
+    from oracle.cases import make_weights
+    sd = make_weights(case["cfg"])
+    den = lambda a, b, c: unet_ref.unet_forward(sd, case["cfg"], a, b, c)
+    gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine", -20.0, 20.0), T, "v", "fixed_large", "snr_trunc", "mse", w_guide=1.0,
+                              p_uncond=0.0, x0eps_coef=True)
+    state = detrand.normal("state", shape, 6)
+    for step in (7, 4, 1, 0):
+        with torch.no_grad():
+            want = dref.p_sample_step(den, dref.make_schedule("cosine"), state, step, T, y, noises[step], model_out_type="v",
+                                      var_type="fixed_large", w_guide=1.0, use_ddim=True, x0eps_coef=True)
+        got = gd.p_sample_step(model, state.to(DEV), torch.full((B,), float(step), device=DEV), y.to(DEV), use_ddim=True)
+        assert (got.cpu() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), step
+
+
+def test_variational_bound_terms_vs_golden(vd, golden_dir):
+    """loss_type="kl" (reference :446-464,497-515): fused KL / decoder-NLL kernel against the reference's per-sample
+    numbers, the analytic backward against the reference's gradients, and the bits/dim decomposition against the oracle.
+    Tolerance: rtol 2e-4 on the per-sample terms -- the decoder likelihood takes log(cdf(a) - cdf(b)) of fp32 tanh-CDFs,
+    whose difference keeps ~4 significant digits for the narrow 8-bit bins."""
+    from oracle import diffusion_ref as dref, unet_ref
+    from oracle.cases import make_weights, kl_case
+    g = _gold(golden_dir, "ext_kl.npz")
+    cfg, x0, t, y, noise, out = kl_case()
+    sched = vd.get_logsnr_schedule("cosine", -20.0, 20.0)
+    for mot, vt, frac in (("v", "fixed_large", None), ("v", "fixed_medium", 0.3), ("eps", "fixed_small", None), ("x0", "fixed_large", None)):
+        model, _ = _build(vd, cfg, train=False)
+        gd = vd.GaussianDiffusion(sched, 8, mot, vt, "snr_trunc", "kl", intp_frac=frac, p_uncond=0.0)
+        loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
+        want = g[f"loss_{mot}_{vt}"]
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), want, rtol=2e-4, atol=2e-5, err_msg=f"{mot}/{vt}")
+        if (mot, vt) == ("v", "fixed_medium"):
+            loss.mean().backward()
+            # the decoder-NLL row's gradient is decided by where fp32 tanh saturates (cdf(a) - cdf(b) becomes exactly 0 and
+            # the clamp kills the gradient): evaluated in fp64 the same expression has a 70 % different gradient (measured
+            # with the oracle), so the reference's fp32 gradient is reproducible only to the last-ulp behaviour of tanh
+            _check_grads(g, model, rel=5e-3)
+    # the two terms on explicit tensors, clipped and not, plus the prediction
+    gd = vd.GaussianDiffusion(sched, 8, "v", "fixed_medium", "snr_trunc", "kl", intp_frac=0.3, p_uncond=0.0)
+    osched = dref.make_schedule("cosine")
+    for step in (0, 3, 7):
+        s = torch.full((6,), step / 8, dtype=torch.float64)
+        tt = torch.full((6,), (step + 1) / 8, dtype=torch.float64)
+        ls, lt = gd.t2logsnr(s, tt, x=x0)
+        xt = dref.q_sample(x0, lt, noise)
+        for clip in (False, True):
+            kl, nll, pred = gd._loss_term_bpd(out.to(DEV), x0.to(DEV), xt.to(DEV), ls.to(DEV), lt.to(DEV), clip, return_pred=True)
+            got = np.stack([kl.cpu().numpy(), nll.cpu().numpy()])
+            np.testing.assert_allclose(got, g[f"terms_{step}_{int(clip)}"], rtol=2e-4, atol=2e-5, err_msg=f"step {step} clip {clip}")
+            _, _, opred = dref.loss_term_bpd(out, x0, xt, ls, lt, "v", "fixed_medium", 0.3, clip)
+            assert (pred.cpu() - opred).abs().max().item() <= 2e-6
+    np.testing.assert_allclose(gd._prior_bpd(x0.to(DEV)).cpu().numpy(), g["prior"], rtol=1e-5, atol=1e-9)
+    # calc_all_bpd: every column equals the oracle's term for that step on the same noise draws
+    model, _ = _build(vd, cfg, train=False)
+    sd = make_weights(cfg)
+    gen = torch.Generator(DEV).manual_seed(77)
+    total, terms, prior, mse = gd.calc_all_bpd(model, x0.to(DEV), y.to(DEV), clip_denoised=True, generator=gen)
+    assert total.shape == (6,) and terms.shape == (6, 8) and mse.shape == (6, 8) and prior.shape == (6,)
+    gen = torch.Generator(DEV).manual_seed(77)
+    for i in range(7, -1, -1):
+        nz = torch.empty(x0.shape, device=DEV).normal_(generator=gen).cpu()
+        s = torch.full((6,), i / 8, dtype=torch.float64)
+        tt = torch.full((6,), (i + 1) / 8, dtype=torch.float64)
+        ls, lt = osched(s).float().reshape(-1, 1, 1, 1), osched(tt).float().reshape(-1, 1, 1, 1)
+        xt = dref.q_sample(x0, lt, nz)
+        with torch.no_grad():
+            o = unet_ref.unet_forward(sd, cfg, xt, tt, y)
+            kl, nll, px0 = dref.loss_term_bpd(o, x0, xt, ls, lt, "v", "fixed_medium", 0.3, True)
+        want = kl if i > 0 else nll
+        np.testing.assert_allclose(terms[:, i].cpu().numpy(), want.numpy(), rtol=5e-4, atol=5e-5, err_msg=f"column {i}")
+        np.testing.assert_allclose(mse[:, i].cpu().numpy(), ((px0 - x0) ** 2).flatten(1).mean(1).numpy(), rtol=5e-4, atol=1e-6)
+    assert torch.allclose(total, terms.sum(1) + prior)
 
 
 # ------------------------------------------------------------------------------------------------ flat-buffer trainer

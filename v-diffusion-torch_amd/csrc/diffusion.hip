@@ -2,6 +2,7 @@
 //   q_sample                         reference v_diffusion/diffusion.py:242-245
 //   train_loss (mse) forward/backward  diffusion.py:466-490,520-541 ; flat_mean functions.py:102-104
 //   one reverse step (p_mean_var + CFG + noise)  diffusion.py:317-392
+//   variational-bound terms (KL / discretised decoder NLL, loss_type "kl") forward/backward  diffusion.py:446-464,497-515
 // All images here are NCHW, the layout of the reference call surface; the UNet converts at its own boundary.
 #include "common.h"
 
@@ -120,6 +121,88 @@ __global__ void loss_bwd_kernel(const LossArgs p, const float* aux, const float*
     }
 }
 
+
+// ---- variational bound terms (diffusion.py:446-464; normal_kl / discretized_gaussian_loglik: functions.py:31-67).
+// coef[b][8] = {a0, b0x, b0e, c1, c2, true_logvar, model_logvar, -}: x0_hat = a0*xt + b0x*o (+ b0e*o_eps),
+// true_mean = c1*xt + c2*x0, model_mean = c1*xt + c2*x0_hat (the posterior mean weights do not depend on the variance type)
+struct BpdArgs {
+    const float* x0; const float* xt; const float* out; const float* coef; int type, clip; int n, C; long long HW;
+};
+constexpr float BPD_PREC = 1.f / 255.f, BPD_CUT = 0.999f, BPD_TOL = 1e-12f, CDF_K = 0.7978845608028654f, CDF_C = 0.044715f;
+
+__device__ __forceinline__ float approx_cdf(float z) { return 0.5f * (1.f + tanhf(CDF_K * (z + CDF_C * z * z * z))); }
+
+// one workgroup per sample: kl[b], nll[b] in bits per dimension, optional x0_hat tensor and its squared error
+__global__ __launch_bounds__(256) void bpd_terms_kernel(const BpdArgs p, float* kl, float* nll, float* pred, float* mse) {
+    __shared__ float sh[8];
+    const int b = blockIdx.x;
+    const float* k = p.coef + 8 * b;
+    const float a0 = k[0], b0x = k[1], b0e = k[2], c1 = k[3], c2 = k[4], tlv = k[5], mlv = k[6];
+    const float d = tlv - mlv, em = expf(-mlv), ed = expf(d), inv = expf(-0.5f * mlv);
+    const long long N = (long long)p.C * p.HW;
+    const int Co = p.type == OUT_BOTH ? 2 * p.C : p.C;
+    const float* ob = p.out + (long long)b * Co * p.HW;
+    float s_kl = 0.f, s_nll = 0.f, s_mse = 0.f;
+    for (long long i = threadIdx.x; i < N; i += blockDim.x) {
+        const float x0 = p.x0[(long long)b * N + i], xt = p.xt[(long long)b * N + i];
+        float x0h = a0 * xt + b0x * ob[i] + (p.type == OUT_BOTH ? b0e * ob[N + i] : 0.f);
+        if (p.clip) x0h = fminf(fmaxf(x0h, -1.f), 1.f);
+        const float tm = c1 * xt + c2 * x0, mm = c1 * xt + c2 * x0h;
+        s_kl += 0.5f * ((-1.f - d) + (tm - mm) * (tm - mm) * em + ed);
+        const float xc = x0 - x0h;
+        const float cu = x0 > BPD_CUT ? 1.f : approx_cdf(inv * (xc + BPD_PREC));
+        const float cl = x0 < -BPD_CUT ? 0.f : approx_cdf(inv * (xc - BPD_PREC));
+        s_nll -= logf(fmaxf(cu - cl - BPD_TOL, 0.f) + BPD_TOL);
+        s_mse += (x0h - x0) * (x0h - x0);
+        if (pred) pred[(long long)b * N + i] = x0h;
+    }
+    s_kl = block_sum(s_kl, sh);
+    s_nll = block_sum(s_nll, sh);
+    s_mse = block_sum(s_mse, sh);
+    if (threadIdx.x == 0) {
+        const float sc = 1.f / ((float)N * 0.6931471805599453f);
+        kl[b] = s_kl * sc; nll[b] = s_nll * sc;
+        if (mse) mse[b] = s_mse / (float)N;
+    }
+}
+
+// dout = gloss[b] * d (use_kl[b] ? kl_b : nll_b) / d out    (training runs with clip_denoised = False, diffusion.py:514)
+__global__ void bpd_bwd_kernel(const BpdArgs p, const float* use_kl, const float* gloss, float* dout) {
+    const long long N = (long long)p.C * p.HW, total = (long long)p.n * N;
+    const int Co = p.type == OUT_BOTH ? 2 * p.C : p.C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / N, i = idx % N;
+        const float* k = p.coef + 8 * b;
+        const float a0 = k[0], b0x = k[1], b0e = k[2], c1 = k[3], c2 = k[4], mlv = k[6];
+        const float* ob = p.out + b * Co * p.HW;
+        float* db = dout + b * Co * p.HW;
+        const float x0 = p.x0[idx], xt = p.xt[idx];
+        float x0h = a0 * xt + b0x * ob[i] + (p.type == OUT_BOTH ? b0e * ob[N + i] : 0.f);
+        bool live = true;                                     // clamp passes no gradient outside [-1, 1]
+        if (p.clip) { live = x0h >= -1.f && x0h <= 1.f; x0h = fminf(fmaxf(x0h, -1.f), 1.f); }
+        float gx;                                             // d term_e / d x0_hat
+        if (use_kl[b] != 0.f) {
+            const float tm = c1 * xt + c2 * x0, mm = c1 * xt + c2 * x0h;
+            gx = -(tm - mm) * expf(-mlv) * c2;
+        } else {
+            const float inv = expf(-0.5f * mlv), xc = x0 - x0h;
+            const float zu = inv * (xc + BPD_PREC), zl = inv * (xc - BPD_PREC);
+            const float tu = tanhf(CDF_K * (zu + CDF_C * zu * zu * zu)), tl = tanhf(CDF_K * (zl + CDF_C * zl * zl * zl));
+            const float cu = x0 > BPD_CUT ? 1.f : 0.5f * (1.f + tu);
+            const float cl = x0 < -BPD_CUT ? 0.f : 0.5f * (1.f + tl);
+            const float D = cu - cl - BPD_TOL;
+            // d cdf(z) / d x0_hat = 0.5 (1 - tanh^2) K (1 + 3 C z^2) * (-inv)
+            const float du = x0 > BPD_CUT ? 0.f : 0.5f * (1.f - tu * tu) * CDF_K * (1.f + 3.f * CDF_C * zu * zu) * (-inv);
+            const float dl = x0 < -BPD_CUT ? 0.f : 0.5f * (1.f - tl * tl) * CDF_K * (1.f + 3.f * CDF_C * zl * zl) * (-inv);
+            gx = D >= 0.f ? -(du - dl) / (D + BPD_TOL) : 0.f;
+        }
+        const float g = live ? gloss[b] * gx / ((float)N * 0.6931471805599453f) : 0.f;
+        db[i] = g * b0x;
+        if (p.type == OUT_BOTH) db[N + i] = g * b0e;
+    }
+}
+
 struct StepArgs {
     const float* xt; const float* out; const float* noise; float k[8]; const float* kdev;
     int type, cfg, last, clip; float* xn; float* xdup; int n, C; long long HW;
@@ -198,5 +281,27 @@ extern "C" int vd_sample_step(const float* xt, const float* out, const float* no
     p.type = type; p.cfg = cfg; p.last = last_step; p.clip = clip; p.xn = xn; p.xdup = xdup; p.n = n; p.C = C; p.HW = HW;
     hipLaunchKernelGGL(sample_step_kernel, dim3(grid_for((long long)n * C * HW)), dim3(256), 0, (hipStream_t)stream, p);
     VD_LAUNCH_CHECK("sample_step_kernel");
+    return 0;
+}
+
+extern "C" int vd_bpd_terms(const float* x0, const float* xt, const float* out, const float* coef, int32_t type, int32_t clip,
+                            float* kl, float* nll, float* pred, float* mse, int32_t n, int32_t C, int32_t HW, void* stream) {
+    VD_REQUIRE(type >= 0 && type <= 3, "vd_bpd_terms: bad model_out_type %d", type);
+    VD_REQUIRE(x0 && xt && out && coef && kl && nll, "vd_bpd_terms: null pointer");
+    BpdArgs p = {x0, xt, out, coef, type, clip, n, C, (long long)HW};
+    hipLaunchKernelGGL(bpd_terms_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, p, kl, nll, pred, mse);
+    VD_LAUNCH_CHECK("bpd_terms_kernel");
+    return 0;
+}
+
+extern "C" int vd_bpd_bwd(const float* x0, const float* xt, const float* out, const float* coef, const float* use_kl,
+                          const float* gloss, int32_t type, int32_t clip, float* dout, int32_t n, int32_t C, int32_t HW,
+                          void* stream) {
+    VD_REQUIRE(type >= 0 && type <= 3, "vd_bpd_bwd: bad model_out_type %d", type);
+    VD_REQUIRE(x0 && xt && out && coef && use_kl && gloss && dout, "vd_bpd_bwd: null pointer");
+    BpdArgs p = {x0, xt, out, coef, type, clip, n, C, (long long)HW};
+    hipLaunchKernelGGL(bpd_bwd_kernel, dim3(grid_for((long long)n * C * HW)), dim3(256), 0, (hipStream_t)stream, p, use_kl, gloss,
+                       dout);
+    VD_LAUNCH_CHECK("bpd_bwd_kernel");
     return 0;
 }

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "vd_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "vd_bpd_terms": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vd_bpd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "vd_sample_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(_f32), _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumsq_ws_bytes": (_sz, [_i64]),
     "vd_sumsq": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
@@ -308,6 +310,16 @@ def loss_fwd(x0, eps, xt, out, logsnr, mot, rw, loss, aux, n, Cc, HW):
 def loss_bwd(x0, eps, xt, out, logsnr, aux, gloss, mot, rw, dout, n, Cc, HW):
     _check(lib().vd_loss_bwd(ptr(x0), ptr(eps), ptr(xt), ptr(out), ptr(logsnr), ptr(aux), ptr(gloss), mot, rw, ptr(dout),
                              n, Cc, HW, stream()), "vd_loss_bwd")
+
+
+def bpd_terms(x0, xt, out, coef, mot, clip, kl, nll, pred, mse, n, Cc, HW):
+    _check(lib().vd_bpd_terms(ptr(x0), ptr(xt), ptr(out), ptr(coef), mot, int(clip), ptr(kl), ptr(nll), ptr(pred), ptr(mse),
+                              n, Cc, HW, stream()), "vd_bpd_terms")
+
+
+def bpd_bwd(x0, xt, out, coef, use_kl, gloss, mot, clip, dout, n, Cc, HW):
+    _check(lib().vd_bpd_bwd(ptr(x0), ptr(xt), ptr(out), ptr(coef), ptr(use_kl), ptr(gloss), mot, int(clip), ptr(dout),
+                            n, Cc, HW, stream()), "vd_bpd_bwd")
 
 
 def sample_step(xt, out, noise, k8, mot, cfg, last, clip, xn, xdup, n, Cc, HW, k_dev=None):

@@ -11,7 +11,7 @@ What runs where
   * ``denoise_fn`` stays an opaque callable ``(x_t, t, y) -> model_out`` exactly as in the reference (:374,:508).
 
 MI355X only: CPU tensors raise (the CPU restatement is oracle/diffusion_ref.py, test infrastructure).
-Out of scope: ``loss_type="kl"`` and the bits-per-dim evaluators.
+``loss_type="kl"`` (variational-bound terms, reference :446-464) is one fused kernel pair as well (vd_bpd_terms / vd_bpd_bwd).
 """
 import math
 
@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _hip
+from .functions import flat_mean
 
 F64 = torch.float64
 
@@ -71,13 +72,15 @@ def get_logsnr_schedule(schedule, logsnr_min: float = -20., logsnr_max: float = 
 # ------------------------------------------------------------------------------------------------ posterior coefficients
 def logsnr_to_posterior(logsnr_s, logsnr_t, var_type: str, intp_frac: float = None, x0eps_coef: bool = False):
     """E[x_s | x_t, x_0] = c1 * x_t + c2 * x_0 and log-variance, fp64 inside, fp32 out (reference :126-163)."""
-    if x0eps_coef:
-        raise NotImplementedError("x0eps_coef=True is not on the hot path (defaults.json:47)")
     ls, lt = logsnr_s.to(F64), logsnr_t.to(F64)
     logr = lt - ls
     l1mr = stable_log1mexp(logr)
-    c1 = torch.exp(logr + 0.5 * (F.logsigmoid(ls) - F.logsigmoid(lt)))
-    c2 = torch.exp(l1mr + 0.5 * F.logsigmoid(ls))
+    if x0eps_coef:                                    # E[x_s | x_t] = c1 * eps + c2 * x_0 (reference :137-140)
+        c1 = torch.exp(0.5 * (F.logsigmoid(ls) - lt) + logr)
+        c2 = torch.sigmoid(ls).sqrt()
+    else:
+        c1 = torch.exp(logr + 0.5 * (F.logsigmoid(ls) - F.logsigmoid(lt)))
+        c2 = torch.exp(l1mr + 0.5 * F.logsigmoid(ls))
     lv_small, lv_large = l1mr + F.logsigmoid(-ls), l1mr + F.logsigmoid(-lt)
     if var_type == "fixed_large":
         lv = lv_large
@@ -92,17 +95,29 @@ def logsnr_to_posterior(logsnr_s, logsnr_t, var_type: str, intp_frac: float = No
 
 
 def logsnr_to_posterior_ddim(logsnr_s, logsnr_t, eta: float = 0., x0eps_coef: bool = False):
-    """DDIM posterior (reference :169-203).  eta = 0 and eta = 1 only (the values the samplers use)."""
-    if x0eps_coef:
-        raise NotImplementedError("x0eps_coef=True is not on the hot path")
+    """DDIM posterior (reference :169-203): eta = 0 deterministic, eta = 1 the fixed_small DDPM posterior, 0 < eta < 1
+    in between.  Quirk kept from the reference (:180-182): with ``eta = 0`` and ``x0eps_coef`` it returns the LOGARITHMS
+    of (sigma_s, alpha_s) -- the exp is missing there -- and its sampler multiplies with those values."""
     ls, lt = logsnr_s.to(F64), logsnr_t.to(F64)
     if eta == 1.:
         return logsnr_to_posterior(ls, lt, "fixed_small")
-    if eta != 0.:
-        raise NotImplementedError("0 < eta < 1 is not used by any sampler of the reference")
-    c1 = torch.exp(0.5 * (F.logsigmoid(-ls) - F.logsigmoid(-lt)))
-    c2 = torch.exp(stable_log1mexp(0.5 * (lt - ls)) + 0.5 * F.logsigmoid(ls))
-    return c1.float(), c2.float(), torch.as_tensor(-math.inf)
+    logr = lt - ls
+    if eta == 0:
+        if x0eps_coef:
+            c1, c2 = 0.5 * F.logsigmoid(-ls), 0.5 * F.logsigmoid(ls)
+        else:
+            c1 = torch.exp(0.5 * (F.logsigmoid(-ls) - F.logsigmoid(-lt)))
+            c2 = torch.exp(stable_log1mexp(0.5 * logr) + 0.5 * F.logsigmoid(ls))
+        return c1.float(), c2.float(), torch.as_tensor(-math.inf)
+    l1mr = stable_log1mexp(logr)
+    logvar = l1mr + F.logsigmoid(-ls) + 2 * math.log(eta)
+    w = stable_log1mexp(2 * math.log(eta) + l1mr)
+    if x0eps_coef:
+        c1, c2 = 0.5 * (w + F.logsigmoid(-ls)), 0.5 * F.logsigmoid(ls)
+    else:
+        c1 = 0.5 * (w + F.logsigmoid(-ls) - F.logsigmoid(-lt))
+        c2 = stable_log1mexp(0.5 * (logr + w)) + 0.5 * F.logsigmoid(ls)
+    return c1.exp().float(), c2.exp().float(), logvar.float()
 
 
 def _pred_coefs(model_out_type, lt32):
@@ -159,6 +174,32 @@ class _MSELoss(torch.autograd.Function):
         return dout, None, None, None, None, None, None
 
 
+class _KLLoss(torch.autograd.Function):
+    """where(s > 0, KL, decoder NLL) per sample in bits/dim (reference :510-515) with its analytic gradient wrt the output."""
+
+    @staticmethod
+    def forward(ctx, out, x0, xt, coef, use_kl, mot):
+        B, C = x0.shape[:2]
+        HW = x0[0, 0].numel()
+        out = out.contiguous()
+        kl = torch.empty((B,), dtype=torch.float32, device=x0.device)
+        nll = torch.empty_like(kl)
+        with torch.cuda.device(x0.device):
+            _hip.bpd_terms(x0, xt, out, coef, mot, False, kl, nll, None, None, B, C, HW)
+        ctx.save_for_backward(out, x0, xt, coef, use_kl)
+        ctx.cfg = (mot, B, C, HW)
+        return torch.where(use_kl != 0, kl, nll)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        out, x0, xt, coef, use_kl = ctx.saved_tensors
+        mot, B, C, HW = ctx.cfg
+        dout = torch.empty_like(out)
+        with torch.cuda.device(x0.device):
+            _hip.bpd_bwd(x0, xt, out, coef, use_kl, gloss.to(torch.float32).contiguous(), mot, False, dout, B, C, HW)
+        return dout, None, None, None, None, None
+
+
 class GaussianDiffusion:
     def __init__(self, logsnr_fn, sample_timesteps, model_out_type, model_var_type, reweight_type, loss_type,
                  intp_frac=None, w_guide=0.1, p_uncond=0.1, x0eps_coef=False):
@@ -172,8 +213,6 @@ class GaussianDiffusion:
         self.w_guide = w_guide
         self.p_uncond = p_uncond
         self.x0eps_coef = x0eps_coef
-        if x0eps_coef:
-            raise NotImplementedError("x0eps_coef=True is not on the hot path (defaults.json:47)")
 
     def t2logsnr(self, *ts, x=None):
         """logsnr(t) reshaped to (B,1,1,..) in x's dtype (reference :293-295)"""
@@ -190,11 +229,12 @@ class GaussianDiffusion:
     # coefficients.  They are small compositions of device tensor ops kept for callers of the reference API.
     def q_posterior_mean_var(self, x_0, x_t, logsnr_s, logsnr_t, model_var_type=None, intp_frac=None):
         c1, c2, logvar = logsnr_to_posterior(logsnr_s, logsnr_t, var_type=model_var_type or self.model_var_type,
-                                             intp_frac=self.intp_frac if intp_frac is None else intp_frac)
+                                             intp_frac=self.intp_frac if intp_frac is None else intp_frac,
+                                             x0eps_coef=self.x0eps_coef)
         return c1 * x_t + c2 * x_0, logvar
 
     def q_posterior_mean_var_ddim(self, x_0, x_t, logsnr_s, logsnr_t):
-        c1, c2, logvar = logsnr_to_posterior_ddim(logsnr_s, logsnr_t, eta=0.)
+        c1, c2, logvar = logsnr_to_posterior_ddim(logsnr_s, logsnr_t, eta=0., x0eps_coef=self.x0eps_coef)
         return c1 * x_t + c2 * x_0, logvar
 
     def p_mean_var(self, model_out, x_t, logsnr_s, logsnr_t, clip_denoised, return_pred, use_ddim=False):
@@ -215,6 +255,11 @@ class GaussianDiffusion:
             raise NotImplementedError(self.model_out_type)
         if clip_denoised:
             pred = pred.clamp(-1., 1.)
+        if self.x0eps_coef:                    # posterior over (eps, x0): eps re-derived from the clipped x0 (reference :338-347)
+            if clip_denoised or self.model_out_type != "eps":
+                x_t = (x_t - s1.sqrt() * pred) * s0.rsqrt()
+            else:
+                x_t = model_out
         if use_ddim:
             mean, logvar = self.q_posterior_mean_var_ddim(pred, x_t, logsnr_s, logsnr_t)
         else:
@@ -226,8 +271,10 @@ class GaussianDiffusion:
         """Per-sample loss (B,) -- reference :492-545, mse branch.  ``y`` is mutated in place by the label drop
         (after the forward, reference quirk :527-529), which consumes one ``torch.rand(B)`` of the global CPU RNG."""
         _need_cuda(x_0, "train_loss")
+        if self.loss_type == "kl":
+            return self._train_loss_kl(denoise_fn, x_0, t, y, noise)
         if self.loss_type != "mse":
-            raise NotImplementedError("loss_type='kl' (bits-per-dim path, reference :446-464) is out of scope of the HIP hot path")
+            raise NotImplementedError(self.loss_type)
         assert self.model_var_type != "learned"
         assert self.reweight_type in _hip.REWEIGHTS and self.model_out_type in _hip.OUT_TYPES
         if noise is None:
@@ -249,6 +296,108 @@ class GaussianDiffusion:
             raise RuntimeError(f"the size of target {tuple(x_0.shape)} must match model_out {tuple(model_out.shape)}")
         return _MSELoss.apply(model_out.to(torch.float32), x_0, noise, x_t, logsnr32, mot, rw)
 
+
+    # ------------------------------------------------------------------------------------------ variational bound (loss_type "kl")
+    def _bpd_coefs(self, logsnr_s, logsnr_t):
+        """coef[B][8] of vd_bpd_terms from per-sample (B,) log-SNRs: fp64 posterior arithmetic on the (tiny) vectors,
+        fp32 prediction weights as reference :206-239 evaluates them."""
+        if self.model_var_type == "learned":
+            raise NotImplementedError("model_var_type='learned'")
+        if self.x0eps_coef:
+            raise NotImplementedError("x0eps_coef=True with the bits-per-dim terms")
+        ls, lt = logsnr_s.reshape(-1).to(torch.float32), logsnr_t.reshape(-1).to(torch.float32)
+        c1, c2, tlv = logsnr_to_posterior(ls, lt, "fixed_small")
+        _, _, mlv = logsnr_to_posterior(ls, lt, self.model_var_type, self.intp_frac)
+        s1, s0 = torch.sigmoid(lt), torch.sigmoid(-lt)
+        z = torch.zeros_like(lt)
+        if self.model_out_type == "v":
+            a0, b0x, b0e = s1.sqrt(), -s0.sqrt(), z
+        elif self.model_out_type == "x0":
+            a0, b0x, b0e = z, torch.ones_like(lt), z
+        elif self.model_out_type == "eps":
+            a0, b0x, b0e = s1.rsqrt(), -torch.exp(-0.5 * lt), z
+        elif self.model_out_type == "both":
+            a0, b0x, b0e = s1.rsqrt() * s1, s0, -torch.exp(-0.5 * lt) * s1
+        else:
+            raise NotImplementedError(self.model_out_type)
+        return torch.stack([a0, b0x, b0e, c1, c2, tlv, mlv, z], dim=1).contiguous()
+
+    def _loss_term_bpd(self, model_out, x_0, x_t, logsnr_s, logsnr_t, clip_denoised, return_pred=False):
+        """(kl, decoder_nll[, pred_x_0]) per sample in bits per dimension -- reference :446-464, one fused kernel."""
+        _need_cuda(x_0, "_loss_term_bpd")
+        x_0, x_t = x_0.to(torch.float32).contiguous(), x_t.to(torch.float32).contiguous()
+        out = model_out.to(torch.float32).contiguous()
+        B, C = x_0.shape[:2]
+        HW = x_0[0, 0].numel()
+        coef = self._bpd_coefs(logsnr_s, logsnr_t)
+        kl = torch.empty((B,), dtype=torch.float32, device=x_0.device)
+        nll = torch.empty_like(kl)
+        pred = torch.empty_like(x_0) if return_pred else None
+        with torch.cuda.device(x_0.device):
+            _hip.bpd_terms(x_0, x_t, out, coef, _hip.OUT_TYPES[self.model_out_type], clip_denoised, kl, nll, pred, None, B, C, HW)
+        return (kl, nll, pred) if return_pred else (kl, nll)
+
+    def _train_loss_kl(self, denoise_fn, x_0, t, y, noise):
+        """un-weighted bound term per sample (reference :497-515): t snapped up to the sampling grid, s = t - 1/T,
+        KL(q || p) where s > 0 and the discretised decoder NLL for the last step."""
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        x_0 = x_0.to(torch.float32).contiguous()
+        noise = noise.to(torch.float32).contiguous()
+        B, C = x_0.shape[:2]
+        HW = x_0[0, 0].numel()
+        T = self.sample_timesteps
+        t = torch.ceil(t * T).div(T)
+        s = t.sub(1 / T).clamp(min=0.)
+        use_kl = (s != 0).to(torch.float32)
+        lt32 = self.logsnr_fn(t).to(torch.float32).reshape(-1).contiguous()
+        ls32 = self.logsnr_fn(s).to(torch.float32).reshape(-1)
+        x_t = torch.empty_like(x_0)
+        with torch.cuda.device(x_0.device):
+            _hip.q_sample(x_0, noise, lt32, x_t, B, C, HW)
+        model_out = denoise_fn(x_t, t, y)
+        coef = self._bpd_coefs(ls32, lt32)
+        return _KLLoss.apply(model_out.to(torch.float32), x_0, x_t, coef, use_kl, _hip.OUT_TYPES[self.model_out_type])
+
+    def _prior_bpd(self, x_0):
+        """KL(q(x_1 | x_0) || N(0, I)) per sample in bits/dim.  Reference :547-553 (its ``logsnr_t, = ...`` only unpacks for
+        a batch of one; this is the same expression for any batch).  A (B,)-vector reduction of tensor ops, not a kernel."""
+        B = x_0.shape[0]
+        lt = self.logsnr_fn(torch.ones((B,), dtype=torch.float32, device=x_0.device)).reshape((-1,) + (1,) * (x_0.ndim - 1))
+        mean, logvar = x_0 * torch.sigmoid(lt).sqrt(), F.logsigmoid(-lt)
+        kl = 0.5 * (-1.0 - logvar + mean.pow(2) + torch.exp(logvar))
+        return flat_mean(kl) / math.log(2.)
+
+    def calc_all_bpd(self, denoise_fn, x_0, y, clip_denoised=True, generator=None):
+        """Bits-per-dimension decomposition over all sampling steps: (total_bpd (B,), terms (B,T), prior (B,), mse (B,T)),
+        all on x_0's device.  Reference :555-576 states this loop but cannot run as written (it unpacks ``x_0.shape`` into
+        the batch size and the 3-tuple of ``_loss_term_bpd`` into two names); the evident intent -- L_0 = decoder NLL,
+        L_i = KL for i > 0, as the commented ``torch.where(s > 0, kl, decoder_nll)`` at :462 says -- is implemented."""
+        _need_cuda(x_0, "calc_all_bpd")
+        x_0 = x_0.to(torch.float32).contiguous()
+        B, C = x_0.shape[:2]
+        HW = x_0[0, 0].numel()
+        T = self.sample_timesteps
+        dev = x_0.device
+        loss = torch.zeros((B, T), dtype=torch.float32, device=dev)
+        mse = torch.zeros((B, T), dtype=torch.float32, device=dev)
+        kl, nll, ms = (torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(3))
+        x_t = torch.empty_like(x_0)
+        mot = _hip.OUT_TYPES[self.model_out_type]
+        with torch.cuda.device(dev):
+            for i in range(T - 1, -1, -1):
+                s = torch.full((B,), i / T, dtype=F64, device=dev)
+                t = torch.full((B,), (i + 1) / T, dtype=F64, device=dev)
+                ls32, lt32 = self.logsnr_fn(s).to(torch.float32), self.logsnr_fn(t).to(torch.float32)
+                noise = torch.empty_like(x_0).normal_(generator=generator)
+                _hip.q_sample(x_0, noise, lt32.contiguous(), x_t, B, C, HW)
+                out = denoise_fn(x_t, t, y).to(torch.float32).contiguous()
+                _hip.bpd_terms(x_0, x_t, out, self._bpd_coefs(ls32, lt32), mot, clip_denoised, kl, nll, None, ms, B, C, HW)
+                loss[:, i] = kl if i > 0 else nll
+                mse[:, i] = ms
+        prior = self._prior_bpd(x_0)
+        return loss.sum(dim=1) + prior, loss, prior, mse
+
     # ------------------------------------------------------------------------------------------ sampling
     def _step_coefs(self, step, use_ddim):
         """The 8 floats of vd_sample_step for reverse step ``step`` (python int)."""
@@ -257,12 +406,19 @@ class GaussianDiffusion:
         l = self.logsnr_fn(st)
         ls32, lt32 = l[0:1].float(), l[1:2].float()            # cast to the image dtype before the posterior (:365)
         if use_ddim:
-            c1, c2, lv = logsnr_to_posterior_ddim(ls32, lt32, eta=0.)
+            c1, c2, lv = logsnr_to_posterior_ddim(ls32, lt32, eta=0., x0eps_coef=self.x0eps_coef)
         else:
-            c1, c2, lv = logsnr_to_posterior(ls32, lt32, self.model_var_type, self.intp_frac)
+            c1, c2, lv = logsnr_to_posterior(ls32, lt32, self.model_var_type, self.intp_frac, x0eps_coef=self.x0eps_coef)
         a0, b0x, b0e = _pred_coefs(self.model_out_type, lt32[0])
         nscale = float(torch.exp(0.5 * lv.float().reshape(-1)[0])) if step > 0 else 0.0
-        return [a0, b0x, b0e, float(c1.reshape(-1)[0]), float(c2.reshape(-1)[0]), nscale, float(self.w_guide), 0.0]
+        c1, c2 = float(c1.reshape(-1)[0]), float(c2.reshape(-1)[0])
+        if self.x0eps_coef:
+            # mean = c1*eps + c2*x0_hat with eps = (x_t - alpha*x0_hat)/sigma (reference :338-347; for an eps-network without
+            # clipping eps is the raw output, the same number): folded on the host into weights of (x_t, x0_hat)
+            l = lt32[0].double()
+            alpha, rsig = float(torch.sigmoid(l).sqrt()), float(torch.sigmoid(-l).rsqrt())
+            c1, c2 = c1 * rsig, c2 - c1 * alpha * rsig
+        return [a0, b0x, b0e, c1, c2, nscale, float(self.w_guide), 0.0]
 
     def _use_cfg(self, y):
         return (self.w_guide > 0) and (y is not None)
