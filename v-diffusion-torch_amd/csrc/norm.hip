@@ -347,6 +347,142 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const BwdApplyArgs a,
     }
 }
 
+
+// ---- single-pass GroupNorm backward.  One workgroup owns (image b, a slab of CS channels = whole groups, >= 96 B per
+// pixel) and ALL pixels of the image: the forward input and the upstream gradient are read ONCE into registers (NPT
+// float4 pairs per thread), the per-channel sums are reduced through LDS, the per-group means follow in the same
+// workgroup, and dx is written from the registers.  HBM traffic is (dy + x) in, dx out -- the two-pass form below reads
+// dy and x twice -- and the dropout mask (Philox) is regenerated once instead of twice.
+struct FusedBwdArgs {
+    BwdApplyArgs a; const float* gamma; const float* beta; const float* film; float* dfilm; float* pgb; int G, CS;
+};
+
+template <int NPT, int TPB>
+__global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f) {
+    __shared__ float red[TPB][8];
+    __shared__ float chs[2][128];        // per-channel S1 (sum dz), S2 (sum dz*xhat) ; later k*S1, k*S2
+    __shared__ float gm[2][32];
+    const ReduceArgs& p = f.a.r;
+    const int b = blockIdx.y, c0 = blockIdx.x * f.CS, CS = f.CS, C = p.C;
+    const int vecs = CS >> 2, rows = TPB / vecs, tid = threadIdx.x;
+    const int r = tid / vecs, v = tid - r * vecs, c4 = c0 + 4 * v;
+    const bool act = r < rows;
+    const int HW = (int)p.HW;
+    const float* cf = p.coef + (long long)b * 4 * C;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f}, nr = sc, nm = of;
+    if (act) {
+        sc = *reinterpret_cast<const f32x4*>(cf + c4);
+        of = *reinterpret_cast<const f32x4*>(cf + C + c4);
+        nr = *reinterpret_cast<const f32x4*>(cf + 2 * C + c4);
+        nm = *reinterpret_cast<const f32x4*>(cf + 3 * C + c4);
+    }
+    const long long HWo = p.resample == VD_RS_DOWN ? p.HW / 4 : (p.resample == VD_RS_UP ? p.HW * 4 : p.HW);
+    const float* dimg = p.dy + (long long)b * HWo * p.lddy;
+    const float* ximg = p.x + (long long)b * p.HW * p.ldx;
+    const int vtot = C >> 2;
+    f32x4 xv[NPT], dz[NPT];
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int pix = r + i * rows;
+        xv[i] = a0 * 0.f; dz[i] = xv[i];
+        if (act && pix < HW) {
+            const f32x4 xin = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
+            const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
+            dz[i] = dz_of(p, dimg, pix, c4, xin, sc, of, vi);
+            xv[i] = xin * nr + nm;                          // keep x_hat: all the second half needs
+            a0 += dz[i];
+            a1 += dz[i] * xv[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid][j] = act ? a0[j] : 0.f; red[tid][4 + j] = act ? a1[j] : 0.f; }
+    __syncthreads();
+    // two-level fixed-order reduction over the `rows` pixel lanes of every (channel vector, component)
+    {
+        const int comps = vecs * 8;                       // (v, j) pairs
+        const int fan = TPB / comps > 16 ? 16 : (TPB / comps < 1 ? 1 : TPB / comps);   // partial sums per pair
+        const int per = (rows + fan - 1) / fan;
+        float part = 0.f;
+        const int pair = tid / fan, k = tid - pair * fan;
+        if (pair < comps) {
+            const int vv = pair >> 3, jj = pair & 7;
+            for (int q = k * per; q < min(rows, (k + 1) * per); ++q) part += red[q * vecs + vv][jj];
+        }
+        __syncthreads();
+        if (pair < comps) red[tid][0] = part;
+        __syncthreads();
+        if (tid < comps) {
+            float s = 0.f;
+            for (int k2 = 0; k2 < fan; ++k2) s += red[tid * fan + k2][0];
+            const int vv = tid >> 3, jj = tid & 7;
+            chs[jj >> 2][vv * 4 + (jj & 3)] = s;
+        }
+        __syncthreads();
+    }
+    const int cg = C / f.G;
+    if (tid < CS) {
+        const int c = c0 + tid;
+        const float s1 = chs[0][tid], s2 = chs[1][tid];
+        float fs = 1.f;
+        if (f.film) {
+            fs = 1.f + f.film[(long long)b * 2 * C + C + c];
+            f.dfilm[(long long)b * 2 * C + c] = s1;
+            f.dfilm[(long long)b * 2 * C + C + c] = f.gamma[c] * s2 + f.beta[c] * s1;
+        }
+        const float k = f.gamma[c] * fs;
+        f.pgb[((long long)b * 2) * C + c] = fs * s2;
+        f.pgb[((long long)b * 2 + 1) * C + c] = fs * s1;
+        chs[0][tid] = k * s1; chs[1][tid] = k * s2;
+    }
+    __syncthreads();
+    if (tid < CS / cg) {
+        float m1 = 0.f, m2 = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { m1 += chs[0][c]; m2 += chs[1][c]; }
+        const float inv = 1.f / ((float)cg * (float)p.HW);
+        gm[0][tid] = m1 * inv; gm[1][tid] = m2 * inv;
+    }
+    __syncthreads();
+    if (!act) return;
+    f32x4 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cl = 4 * v + j, c = c0 + cl, g = cl / cg;
+        const float fs = f.film ? 1.f + f.film[(long long)b * 2 * C + C + c] : 1.f;
+        q0[j] = nr[j] * f.gamma[c] * fs; q1[j] = nr[j] * gm[0][g]; q2[j] = nr[j] * gm[1][g];
+    }
+    const float* aimg = f.a.add ? f.a.add + (long long)b * p.HW * f.a.ldadd : nullptr;
+    float* oimg = f.a.dx + (long long)b * p.HW * f.a.lddx;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int pix = r + i * rows;
+        if (pix >= HW) continue;
+        f32x4 d = q0 * dz[i] - q1 - xv[i] * q2;
+        if (aimg) d += *reinterpret_cast<const f32x4*>(aimg + (long long)pix * f.a.ldadd + c4);
+        float* o = oimg + (long long)pix * f.a.lddx + c4;
+        if (f.a.accumulate_dx) d += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = d;
+    }
+}
+
+template <int TPB>
+void launch_fused_bwd(int npt, dim3 grid, hipStream_t st, const FusedBwdArgs& f) {
+    if (npt <= 1) hipLaunchKernelGGL((gn_bwd_fused_kernel<1, TPB>), grid, dim3(TPB), 0, st, f);
+    else if (npt <= 2) hipLaunchKernelGGL((gn_bwd_fused_kernel<2, TPB>), grid, dim3(TPB), 0, st, f);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_bwd_fused_kernel<4, TPB>), grid, dim3(TPB), 0, st, f);
+    else hipLaunchKernelGGL((gn_bwd_fused_kernel<8, TPB>), grid, dim3(TPB), 0, st, f);
+}
+
+// channel slab of the fused backward: whole groups, a multiple of 4 channels, at least 24 channels (96 B per pixel row)
+inline int fused_slab(int C, int G) {
+    const int cg = C / G;
+    for (int k = 1; k * cg <= 128 && k <= G; ++k) {
+        const int cs = k * cg;
+        if (cs % 4 == 0 && cs >= 24 && C % cs == 0) return cs;
+    }
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int chunks, int N, float* out, int accumulate) {
     __shared__ float sh[16][17];
     const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
@@ -456,6 +592,24 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
         float* q = part + (long long)nimg * p.chunks * 2 * C;
         float* pgb = q + (long long)nimg * 3 * C;
         p.part = part;
+        // single-pass form whenever one workgroup can hold an image's slab in registers (<= 8 float4 pairs per thread)
+        static const bool two_pass = getenv("VD_GN_TWO_PASS") != nullptr;        // A/B switch for profiling
+        const int CS = fused_slab(C, G);
+        if (!two_pass && CS > 0 && nimg <= 65535) {
+            const int TPB = HW * (CS / 4) >= 1024 ? 1024 : 256;
+            const int rows = TPB / (CS / 4);
+            const int npt = (int)((HW + rows - 1) / rows);
+            if (npt <= 8) {
+                FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS};
+                dim3 grid(C / CS, nimg);
+                if (TPB == 1024) launch_fused_bwd<1024>(npt, grid, st, f); else launch_fused_bwd<256>(npt, grid, st, f);
+                VD_LAUNCH_CHECK("gn_bwd_fused_kernel");
+                hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
+                                   accumulate_params);
+                VD_LAUNCH_CHECK("sum_over_images_kernel");
+                return 0;
+            }
+        }
         hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(p.chunks, nimg, C / Cb), dim3(256), 0, st, p, Cb);
         VD_LAUNCH_CHECK("chan_reduce_kernel<1>");
         hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nimg), dim3(256), (2 * C + 2 * G) * sizeof(float), st, part, p.chunks,
