@@ -80,6 +80,20 @@ int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, const float* b
                int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate,
                float* stats_part /* optional: GroupNorm partials of y, see vd_gemm_desc.stats */, void* stream);
 
+/* "thin" 3x3 convolutions (3-4 channels on one side: in_conv unet.py:217, out_conv :232).  The taps are moved to the thin
+ * side so that the wide side is a plain vd_gemm instead of an implicit GEMM with a 64-wide tile on 3 useful columns:
+ *   thin input :  xc = vd_im2col3x3(x) [pixels][9*C]            then  y = vd_gemm(xc, wpack[Cout][9*C])  (+ its transposes)
+ *   thin output:  z  = vd_gemm(a, wpack viewed [9*Cout][Cin])    then  y = vd_tap_gather(z, bias)
+ *   gradients  :  dz = vd_tap_spread(dy);  da = vd_gemm(dz, wpack);  vd_gemm(dz^T a) -> vd_thin_wgrad_finish -> OIHW */
+int vd_im2col3x3(const float* x, int64_t ldx, float* xc /* [nimg*H*W][9*C] */, int32_t nimg, int32_t H, int32_t W, int32_t C, void* stream);
+/* out[p][co] = bias[co] + sum_tap z[p + off(tap)][co*9 + tap]   (zero padding; co < Cout) */
+int vd_tap_gather(const float* z, int64_t ldz, const float* bias, float* out, int64_t ldo, int32_t nimg, int32_t H, int32_t W, int32_t Cout, void* stream);
+/* dz[q][co*9 + tap] = dy[q - off(tap)][co]; columns [9*Cout, ldz) are zero-filled */
+int vd_tap_spread(const float* dy, int64_t lddy, float* dz, int64_t ldz, int32_t nimg, int32_t H, int32_t W, int32_t Cout, void* stream);
+/* g[co][tap*Cin + ci] -> dw_oihw[co][ci][tap] (+)= (ci < Cin_w);  dbias[co] (+)= colsum[co*cs_stride + cs_off] (optional) */
+int vd_thin_wgrad_finish(const float* g, int32_t Cout_w, int32_t Cin, int32_t Cin_w, float* dw_oihw, int32_t accumulate,
+                         const float* colsum, int32_t cs_stride, int32_t cs_off, float* dbias, void* stream);
+
 /* weight (and bias) gradient of the same convolution, summed over the whole batch (autograd of F.conv2d):
  *   dw_oihw[co][ci][tap] (+)= sum_{b,y,x} dy[b,y,x,co] * xin[b,y+dy,x+dx,ci]      co < Cout_w, ci < Cin_w
  *   dbias[co]            (+)= sum_{b,y,x} dy[b,y,x,co]                             (dbias may be NULL)

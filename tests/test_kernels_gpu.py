@@ -193,6 +193,73 @@ def test_conv3x3_wgrad(H, case):
     close(db, dy[:, :Cout_w].double().sum((0, 2, 3)) + 1.0, dy[:, :Cout_w].sum((0, 2, 3)) + 1.0, name="conv dbias")
 
 
+@pytest.mark.parametrize("case", [(3, 8, 8, 32, 3), (2, 16, 12, 64, 6), (1, 4, 4, 32, 1)])
+def test_thin_output_conv_fwd_bwd(H, case):
+    """hid -> 3 convolution as GEMM + 9-tap gather (vd_tap_gather / vd_tap_spread / vd_thin_wgrad_finish) == F.conv2d"""
+    nimg, Hh, Ww, Cin, Cout = case
+    x, w, bias = rnd(nimg, Cin, Hh, Ww, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.2), rnd(Cout, seed=3)
+    dy = rnd(nimg, Cout, Hh, Ww, seed=4)
+    leaves = [t.double().requires_grad_(True) for t in (x, w, bias)]
+    F.conv2d(leaves[0], leaves[1], leaves[2], padding=1).backward(dy.double())
+    l32 = [t.clone().requires_grad_(True) for t in (x, w, bias)]
+    y32 = F.conv2d(l32[0], l32[1], l32[2], padding=1)
+    y32.backward(dy)
+    P, nz, cop = nimg * Hh * Ww, (9 * Cout + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    wz = torch.zeros(nz, Cin, device=DEV)
+    H.pack_conv3x3(w.to(DEV), Cout, Cin, wf=wz, Cin_p=Cin)
+    xa = nhwc(x)
+    z = torch.empty(P, nz, device=DEV)
+    H.gemm(xa, wz, z, P, 9 * Cout, Cin, a_kind=H.ROW, b_kind=H.ROW, lda=Cin, ldb=Cin, ldc=nz)
+    y = torch.zeros(nimg, Hh, Ww, cop, device=DEV)
+    H.tap_gather(z, nz, bias.to(DEV), y, cop, nimg, Hh, Ww, Cout)
+    close(from_nhwc(y, Cout), F.conv2d(x.double(), w.double(), bias.double(), padding=1), y32, name="thin-out fwd")
+    assert float(y[..., Cout:].abs().max()) == 0.0 if cop > Cout else True
+    dyp = torch.zeros(nimg, cop, Hh, Ww)
+    dyp[:, :Cout] = dy
+    dz = torch.full((P, nz), 7.0, device=DEV)
+    H.tap_spread(nhwc(dyp), cop, dz, nz, nimg, Hh, Ww, Cout)
+    gz, cs = torch.empty(nz, Cin, device=DEV), torch.empty(nz, device=DEV)
+    H.gemm(dz, xa, gz, nz, Cin, P, a_kind=H.COL, b_kind=H.COL, lda=nz, ldb=Cin, ldc=Cin, splitk=2 if P >= 512 else 1, colsum=cs)
+    dw, db = torch.ones(Cout, Cin, 3, 3, device=DEV), torch.ones(Cout, device=DEV)
+    H.thin_wgrad_finish(gz, Cout, Cin, Cin, dw, accumulate=True, colsum=cs, cs_stride=9, cs_off=4, dbias=db)
+    close(dw, leaves[1].grad + 1, l32[1].grad + 1, name="thin-out dw")
+    close(db, leaves[2].grad + 1, l32[2].grad + 1, name="thin-out db")
+    dx = torch.empty(nimg, Hh, Ww, Cin, device=DEV)
+    H.gemm(dz, wz, dx, P, Cin, nz, a_kind=H.ROW, b_kind=H.COL, lda=nz, ldb=Cin, ldc=Cin)
+    close(from_nhwc(dx, Cin), leaves[0].grad, l32[0].grad, name="thin-out dx")
+
+
+@pytest.mark.parametrize("case", [(3, 8, 8, 3, 32), (2, 16, 12, 4, 64), (1, 4, 4, 1, 32)])
+def test_thin_input_conv_fwd_wgrad(H, case):
+    """3 -> hid convolution as im2col (vd_im2col3x3) + K = 36 GEMM == F.conv2d, and its weight/bias gradient"""
+    nimg, Hh, Ww, Cin, Cout = case
+    cip = (Cin + 3) // 4 * 4
+    x, w, bias = rnd(nimg, Cin, Hh, Ww, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.3), rnd(Cout, seed=3)
+    dy = rnd(nimg, Cout, Hh, Ww, seed=4)
+    leaves = [t.double().requires_grad_(True) for t in (w, bias)]
+    y64 = F.conv2d(x.double(), leaves[0], leaves[1], padding=1)
+    y64.backward(dy.double())
+    l32 = [t.clone().requires_grad_(True) for t in (w, bias)]
+    y32 = F.conv2d(x, l32[0], l32[1], padding=1)
+    y32.backward(dy)
+    P = nimg * Hh * Ww
+    xp = torch.zeros(nimg, cip, Hh, Ww)
+    xp[:, :Cin] = x
+    xc = torch.full((P, 9 * cip), 5.0, device=DEV)
+    H.im2col3x3(nhwc(xp), cip, xc, nimg, Hh, Ww, cip)
+    wf = torch.empty(Cout, 9, cip, device=DEV)
+    H.pack_conv3x3(w.to(DEV), Cout, Cin, wf=wf, Cin_p=cip)
+    y = torch.empty(nimg, Hh, Ww, Cout, device=DEV)
+    H.gemm(xc, wf, y, P, Cout, 9 * cip, a_kind=H.ROW, b_kind=H.ROW, lda=9 * cip, ldb=9 * cip, ldc=Cout, bias=bias.to(DEV))
+    close(from_nhwc(y, Cout), y64.detach(), y32, name="thin-in fwd")
+    gw, db = torch.empty(Cout, 9 * cip, device=DEV), torch.empty(Cout, device=DEV)
+    H.gemm(nhwc(dy), xc, gw, Cout, 9 * cip, P, a_kind=H.COL, b_kind=H.COL, lda=Cout, ldb=9 * cip, ldc=9 * cip, colsum=db)
+    dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
+    H.thin_wgrad_finish(gw, Cout, cip, Cin, dw)
+    close(dw, leaves[0].grad, l32[0].grad, name="thin-in dw")
+    close(db, leaves[1].grad, l32[1].grad, name="thin-in db")
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm family
 def ref_gn_block(x, gamma, beta, film, act, resample, mask=None):
     B, Cc = x.shape[:2]

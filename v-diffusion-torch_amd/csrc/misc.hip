@@ -215,6 +215,85 @@ __global__ void from_uint8_hwc_kernel(const unsigned char* in, const unsigned ch
     }
 }
 
+
+// ---- "thin" 3x3 convolutions (reference unet.py:217 in_conv 3->C, :232 out_conv C->3).  With 3-4 channels on one side the
+// implicit-GEMM tile engine would burn a 64-wide tile dimension on 3 useful columns; instead the 9 taps are moved to the
+// thin side and the wide side becomes a plain GEMM (vd_gemm):
+//   Cin thin : xc[p][tap*Cin + ci] = x[p + off(tap)][ci]                      (im2col, K = 9*Cin)   -> y = xc . W^T
+//   Cout thin: z[q][co*9 + tap] = sum_ci a[q][ci] w[co][tap][ci]   (GEMM, N = 9*Cout)  -> y[p][co] = b + sum_tap z[p+off(tap)][co*9+tap]
+// and the transposed forms for the gradients.
+__global__ void im2col3x3_kernel(const float* x, long long ldx, float* xc, int nimg, int H, int W, int C) {
+    const int vecs = C >> 2;
+    const long long total = (long long)nimg * H * W * 9 * vecs;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(idx % vecs);
+        const int tap = (int)((idx / vecs) % 9);
+        const long long p = idx / (9 * vecs);
+        const int rem = (int)(p % ((long long)H * W)), y = rem / W, xx = rem % W;
+        const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W)
+            val = *reinterpret_cast<const f32x4*>(x + (p + (long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * ldx + 4 * v);
+        *reinterpret_cast<f32x4*>(xc + p * (9LL * C) + tap * C + 4 * v) = val;
+    }
+}
+
+__global__ void tap_gather_kernel(const float* z, long long ldz, const float* bias, float* out, long long ldo, int nimg, int H,
+                                  int W, int Cout) {
+    const long long total = (long long)nimg * H * W * Cout;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout);
+        const long long p = idx / Cout;
+        const int rem = (int)(p % ((long long)H * W)), y = rem / W, x = rem % W;
+        float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                acc += z[(p + (long long)(tap / 3 - 1) * W + (tap % 3 - 1)) * ldz + co * 9 + tap];
+        }
+        out[p * ldo + co] = acc;
+    }
+}
+
+// dz[q][co*9 + tap] = dy[q - off(tap)][co] (zero outside the image), columns [9*Cout, ldz) zero-filled
+__global__ void tap_spread_kernel(const float* dy, long long lddy, float* dz, long long ldz, int nimg, int H, int W, int Cout) {
+    const long long total = (long long)nimg * H * W * ldz;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % ldz);
+        const long long q = idx / ldz;
+        float v = 0.f;
+        if (col < 9 * Cout) {
+            const int co = col / 9, tap = col % 9;
+            const int rem = (int)(q % ((long long)H * W)), y = rem / W, x = rem % W;
+            const int yy = y - (tap / 3 - 1), xx = x - (tap % 3 - 1);
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                v = dy[(q - (long long)(tap / 3 - 1) * W - (tap % 3 - 1)) * lddy + co];
+        }
+        dz[idx] = v;
+    }
+}
+
+// g[co][tap*Cin + ci] (one GEMM result) -> dw_oihw[(co*Cin_w + ci)*9 + tap] (+)= ; optional dbias[co] (+)= cs[co*cs_stride + cs_off]
+__global__ void thin_wgrad_finish_kernel(const float* g, int Cout_w, int Cin, int Cin_w, float* dw, int accumulate,
+                                         const float* cs, int cs_stride, int cs_off, float* dbias) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dbias && idx < Cout_w) {
+        const float c = cs[idx * cs_stride + cs_off];
+        dbias[idx] = accumulate ? dbias[idx] + c : c;
+    }
+    const long long total = (long long)Cout_w * 9 * Cin;
+    if (idx >= total) return;
+    const int co = (int)(idx / (9 * Cin)), rem = (int)(idx % (9 * Cin));
+    const int tap = rem / Cin, ci = rem % Cin;
+    if (ci >= Cin_w) return;
+    float* o = dw + ((long long)co * Cin_w + ci) * 9 + tap;
+    *o = accumulate ? *o + g[idx] : g[idx];
+}
+
 }  // namespace
 
 extern "C" int vd_images_to_uint8_hwc(const float* x_nchw, uint8_t* out, int32_t n, int32_t C, int32_t HW, void* stream) {
@@ -316,5 +395,43 @@ extern "C" int vd_class_embed_bwd(const float* y, const float* dtemb, float* dw,
 extern "C" int vd_multitag_norm(const float* y, float* out, int32_t n, int32_t ncls, void* stream) {
     hipLaunchKernelGGL(multitag_norm_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, y, out, n, ncls);
     VD_LAUNCH_CHECK("multitag_norm_kernel");
+    return 0;
+}
+
+extern "C" int vd_im2col3x3(const float* x, int64_t ldx, float* xc, int32_t nimg, int32_t H, int32_t W, int32_t C, void* stream) {
+    VD_REQUIRE(x && xc && C % 4 == 0 && ldx % 4 == 0, "vd_im2col3x3: C/ld must be multiples of 4 (C=%d)", C);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((long long)nimg * H * W * 9 * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, xc, nimg, H, W, C);
+    VD_LAUNCH_CHECK("im2col3x3_kernel");
+    return 0;
+}
+
+extern "C" int vd_tap_gather(const float* z, int64_t ldz, const float* bias, float* out, int64_t ldo, int32_t nimg, int32_t H,
+                             int32_t W, int32_t Cout, void* stream) {
+    VD_REQUIRE(z && out && ldz >= 9 * Cout && ldo >= Cout, "vd_tap_gather: bad leading dimensions");
+    hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for((long long)nimg * H * W * Cout)), dim3(256), 0, (hipStream_t)stream, z, ldz,
+                       bias, out, ldo, nimg, H, W, Cout);
+    VD_LAUNCH_CHECK("tap_gather_kernel");
+    return 0;
+}
+
+extern "C" int vd_tap_spread(const float* dy, int64_t lddy, float* dz, int64_t ldz, int32_t nimg, int32_t H, int32_t W,
+                             int32_t Cout, void* stream) {
+    VD_REQUIRE(dy && dz && ldz >= 9 * Cout && lddy >= Cout, "vd_tap_spread: bad leading dimensions");
+    hipLaunchKernelGGL(tap_spread_kernel, dim3(grid_for((long long)nimg * H * W * ldz)), dim3(256), 0, (hipStream_t)stream, dy, lddy,
+                       dz, ldz, nimg, H, W, Cout);
+    VD_LAUNCH_CHECK("tap_spread_kernel");
+    return 0;
+}
+
+extern "C" int vd_thin_wgrad_finish(const float* g, int32_t Cout_w, int32_t Cin, int32_t Cin_w, float* dw_oihw, int32_t accumulate,
+                                    const float* colsum, int32_t cs_stride, int32_t cs_off, float* dbias, void* stream) {
+    VD_REQUIRE(g && dw_oihw && Cin_w <= Cin, "vd_thin_wgrad_finish: bad arguments");
+    VD_REQUIRE(!dbias || colsum, "vd_thin_wgrad_finish: dbias needs the column sums");
+    long long total = (long long)Cout_w * 9 * Cin;
+    if (total < Cout_w) total = Cout_w;
+    hipLaunchKernelGGL(thin_wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, Cout_w,
+                       Cin, Cin_w, dw_oihw, accumulate, colsum, cs_stride, cs_off, dbias);
+    VD_LAUNCH_CHECK("thin_wgrad_finish_kernel");
     return 0;
 }

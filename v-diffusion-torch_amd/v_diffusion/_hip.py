@@ -62,6 +62,10 @@ _SIGNATURES = {
     "vd_class_embed": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_class_embed_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vd_multitag_norm": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "vd_im2col3x3": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vd_tap_gather": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "vd_tap_spread": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "vd_thin_wgrad_finish": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "vd_q_sample": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_loss_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_loss_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
@@ -209,6 +213,23 @@ def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, ac
     with _Timed("gemm_dma_kernel<{tile}, 1, 2, true, {kt}> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w,
                                       int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
+
+
+def im2col3x3(x, ldx, xc, nimg, H, W, Cc):
+    _check(lib().vd_im2col3x3(ptr(x), ldx, ptr(xc), nimg, H, W, Cc, stream()), "vd_im2col3x3")
+
+
+def tap_gather(z, ldz, bias, out, ldo, nimg, H, W, Cout):
+    _check(lib().vd_tap_gather(ptr(z), ldz, ptr(bias), ptr(out), ldo, nimg, H, W, Cout, stream()), "vd_tap_gather")
+
+
+def tap_spread(dy, lddy, dz, ldz, nimg, H, W, Cout):
+    _check(lib().vd_tap_spread(ptr(dy), lddy, ptr(dz), ldz, nimg, H, W, Cout, stream()), "vd_tap_spread")
+
+
+def thin_wgrad_finish(g, Cout_w, Cin, Cin_w, dw, accumulate=False, colsum=None, cs_stride=1, cs_off=0, dbias=None):
+    _check(lib().vd_thin_wgrad_finish(ptr(g), Cout_w, Cin, Cin_w, ptr(dw), int(accumulate), ptr(colsum), cs_stride, cs_off,
+                                      ptr(dbias), stream()), "vd_thin_wgrad_finish")
 
 
 def pack_conv3x3(w, Cout_w, Cin_w, wf=None, Cin_p=0, wd=None, Cout_p=0):

@@ -24,6 +24,7 @@ from . import _hip as H
 
 GROUPS = 32
 EPS = 1e-6
+THIN = 8          # in/out convolutions with at most this many channels on the thin side take the GEMM + tap kernels
 
 
 def _ld(t):
@@ -174,6 +175,19 @@ class UNetEngine:
         wd = self._new(w, ci, 9, cout_p)
         H.pack_conv3x3(w, co, ci, wd=wd, Cout_p=cout_p)
         return wd
+
+    def _pack_thin(self, w, rows):
+        """[rows][Cin] image of a thin-output 3x3 kernel: row co*9+tap = w[co][:, tap], rows beyond 9*Cout are zero"""
+        cache = self.pack_cache
+        key = ("thin", id(w))
+        if cache is not None and key in cache:
+            return cache[key]
+        co, ci = w.shape[0], w.shape[1]
+        wz = torch.zeros((rows, ci), dtype=torch.float32, device=w.device)
+        H.pack_conv3x3(w, co, ci, wf=wz, Cin_p=ci)
+        if cache is not None:
+            cache[key] = wz
+        return wz
 
     @staticmethod
     def _linear(x, w, b, out, accumulate=False):
@@ -470,8 +484,18 @@ class UNetEngine:
         p0 = self.pushes[0]
         d = dest_of(("cat", p0[2], p0[3], p0[1]), H0, W0)
         pp = self._part(x_nchw, B, H0 * W0, m.hid_channels)
-        H.conv3x3(x4, cip, self._pack_f(m.in_conv.weight, cip), m.in_conv.bias, d, _ld(d), B, H0, W0, cip, m.hid_channels,
-                  stats_part=pp)
+        if pp is not None and (H0 * W0) % 64:
+            pp = None
+        xc = None
+        if cip <= THIN:
+            # thin input (3 -> hid): im2col of the 4-channel image once, then a plain K = 36 GEMM (see vd_im2col3x3)
+            xc = self._new(x_nchw, B * H0 * W0, 9 * cip)
+            H.im2col3x3(x4, cip, xc, B, H0, W0, cip)
+            H.gemm(xc, self._pack_f(m.in_conv.weight, cip), d, B * H0 * W0, m.hid_channels, 9 * cip, a_kind=H.ROW, b_kind=H.ROW,
+                   lda=9 * cip, ldb=9 * cip, ldc=_ld(d), bias=m.in_conv.bias, stats=pp, stats_hw=H0 * W0)
+        else:
+            H.conv3x3(x4, cip, self._pack_f(m.in_conv.weight, cip), m.in_conv.bias, d, _ld(d), B, H0, W0, cip, m.hid_channels,
+                      stats_part=pp)
         cat_parts = {p0[2]: {p0[3]: self._parts(pp, m.hid_channels, H0 * W0)}}      # consumer block -> {channel offset: partials}
         hs_top, h = d, None
         top_parts, h_parts = cat_parts[p0[2]][p0[3]], None
@@ -514,11 +538,21 @@ class UNetEngine:
         co = m.out_channels
         cop = (co + 3) // 4 * 4
         out = torch.zeros((B, H0, W0, cop), dtype=torch.float32, device=h.device)
-        H.conv3x3(a, C0, self._pack_f(conv.weight), conv.bias, out, cop, B, H0, W0, C0, co)
+        wz = None
+        if co <= THIN:
+            # thin output (hid -> 3): z[q][co*9+tap] = a[q] . w[co][tap] as a plain GEMM, then the 9-tap gather (vd_tap_gather)
+            nz = (9 * co + 3) // 4 * 4
+            wz = self._pack_thin(conv.weight, nz)
+            z = self._new(h, B * H0 * W0, nz)
+            H.gemm(a, wz, z, B * H0 * W0, 9 * co, C0, a_kind=H.ROW, b_kind=H.ROW, lda=C0, ldb=C0, ldc=nz)
+            H.tap_gather(z, nz, conv.bias, out, cop, B, H0, W0, co)
+            del z
+        else:
+            H.conv3x3(a, C0, self._pack_f(conv.weight), conv.bias, out, cop, B, H0, W0, C0, co)
         if tape is not None:
             tape["ta"] = ta
-            tape["in"] = dict(x4=x4)
-            tape["out"] = dict(h=h, coef=coef, a=a)
+            tape["in"] = dict(x4=x4 if xc is None else None, xc=xc, cip=cip)
+            tape["out"] = dict(h=h, coef=coef, a=a, wz=wz)
         return out, tape
 
     def new_grads(self):
@@ -539,9 +573,22 @@ class UNetEngine:
         gn, conv = m.out_conv[0], m.out_conv[2]
         o = tape["out"]
         co = m.out_channels
-        H.conv3x3_wgrad(o["a"], C0, dout, cop, B, H0, W0, C0, cop, G["out_conv.2.weight"], C0, co, dbias=G["out_conv.2.bias"])
+        P0 = B * H0 * W0
         da = self._new(dout, B, H0, W0, C0)
-        H.conv3x3(dout, cop, self._pack_d(conv.weight, cop), None, da, C0, B, H0, W0, cop, C0)
+        if o["wz"] is not None:
+            wz = o["wz"]
+            nz = wz.shape[0]
+            dz = self._new(dout, P0, nz)
+            H.tap_spread(dout, cop, dz, nz, B, H0, W0, co)                   # dz[q][co*9+tap] = dout[q - off(tap)][co]
+            gz, cs = self._new(dout, nz, C0), self._new(dout, nz)
+            H.gemm(dz, o["a"], gz, nz, C0, P0, a_kind=H.COL, b_kind=H.COL, lda=nz, ldb=C0, ldc=C0, splitk=_splitk(nz, C0, P0),
+                   colsum=cs)
+            H.thin_wgrad_finish(gz, co, C0, C0, G["out_conv.2.weight"], colsum=cs, cs_stride=9, cs_off=4, dbias=G["out_conv.2.bias"])
+            H.gemm(dz, wz, da, P0, C0, nz, a_kind=H.ROW, b_kind=H.COL, lda=nz, ldb=C0, ldc=C0)
+            del dz
+        else:
+            H.conv3x3_wgrad(o["a"], C0, dout, cop, B, H0, W0, C0, cop, G["out_conv.2.weight"], C0, co, dbias=G["out_conv.2.bias"])
+            H.conv3x3(dout, cop, self._pack_d(conv.weight, cop), None, da, C0, B, H0, W0, cop, C0)
         dh = self._new(dout, B, H0, W0, C0)
         H.gn_apply_bwd(da, C0, o["h"], _ld(o["h"]), o["coef"], gn.weight, gn.bias, None, 1, 0.0, 0, H.RS_NONE, None, 0, dh, C0,
                        False, None, G["out_conv.0.weight"], G["out_conv.0.bias"], False, B, H0, W0, C0, GROUPS)
@@ -583,10 +630,16 @@ class UNetEngine:
         # ---- in_conv
         dy0 = dskip.pop(0)
         assert not dskip
-        x4 = tape["in"]["x4"]
-        cip = x4.shape[3]
-        H.conv3x3_wgrad(x4, cip, dy0, _ld(dy0), B, H0, W0, cip, m.hid_channels, G["in_conv.weight"], m.in_channels, m.hid_channels,
-                        dbias=G["in_conv.bias"])
+        xc, cip = tape["in"]["xc"], tape["in"]["cip"]
+        hid = m.hid_channels
+        if xc is not None:
+            gw = self._new(dout, hid, 9 * cip)
+            H.gemm(dy0, xc, gw, hid, 9 * cip, P0, a_kind=H.COL, b_kind=H.COL, lda=_ld(dy0), ldb=9 * cip, ldc=9 * cip,
+                   splitk=_splitk(hid, 9 * cip, P0), colsum=G["in_conv.bias"])
+            H.thin_wgrad_finish(gw, hid, cip, m.in_channels, G["in_conv.weight"])
+        else:
+            H.conv3x3_wgrad(tape["in"]["x4"], cip, dy0, _ld(dy0), B, H0, W0, cip, hid, G["in_conv.weight"], m.in_channels, hid,
+                            dbias=G["in_conv.bias"])
         progress("in_conv.bias")
         dx = None
         if need_dx:
