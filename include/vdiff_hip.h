@@ -124,10 +124,16 @@ int vd_gn_stats(const float* x, int64_t ldx, int32_t nimg, int32_t HW, int32_t C
 int vd_gn_stats_from_partials(const float* part1, int32_t C1, int32_t chunks1, const float* part2, int32_t C2, int32_t chunks2,
                               int32_t nimg, int32_t HW, int32_t G, float eps, float* stats, void* stream);
 
+/* ... or straight to the coefficient table vd_gn_apply works from (then call vd_gn_apply with stats = NULL) */
+int vd_gn_coef_from_partials(const float* part1, int32_t C1, int32_t chunks1, const float* part2, int32_t C2, int32_t chunks2,
+                             int32_t nimg, int32_t HW, int32_t G, float eps, const float* gamma, const float* beta,
+                             const float* film, float* coef, void* stream);
+
 /* y = resample( dropout( act( (1+scale) * GN(x) + shift ) ) )
  * film: [nimg][2C] (shift first, scale second, unet.py:145) or NULL; act: 1 = SiLU, 0 = identity;
  * gamma/beta NULL => plain resample of x (the skip path, unet.py:138).
- * coef: scratch [nimg][4][C] floats, kept for the backward pass. */
+ * coef: [nimg][4][C] floats, kept for the backward pass; written here from `stats`, or -- with stats = NULL -- already
+ * filled by vd_gn_coef_from_partials. */
 int vd_gn_apply(const float* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                 const float* film, int32_t act, float p_drop, uint64_t seed,
                 int32_t resample, float* y, int64_t ldy,

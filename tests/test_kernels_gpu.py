@@ -364,6 +364,14 @@ def test_gn_stats_from_producer_epilogues(H, case):
     close(stats[..., 0], mean, None, floor=2e-6, name="mean")
     close(stats[..., 1], 1 / torch.sqrt(var + 1e-6), None, floor=5e-6, name="rstd")
     close(direct[..., 1], 1 / torch.sqrt(var + 1e-6), None, floor=5e-6, name="rstd direct")
+    # partials -> coefficient table in one kernel (vd_gn_coef_from_partials) == statistics + vd_gn_apply's own table
+    gamma, beta, film = rnd(Ct, seed=7).to(DEV), rnd(Ct, seed=8).to(DEV), (rnd(nimg, 2 * Ct, seed=9) * 0.1).to(DEV)
+    y_a, y_b = torch.empty_like(buf), torch.empty_like(buf)
+    coef_a, coef_b = torch.empty(nimg, 4, Ct, device=DEV), torch.full((nimg, 4, Ct), 3.0, device=DEV)
+    H.gn_apply(buf, Ct, stats, gamma, beta, film, 1, 0.0, 0, H.RS_NONE, y_a, Ct, nimg, Hh, Ww, Ct, coef_a)
+    H.gn_coef_from_partials(parts, nimg, HW, gamma, beta, film, coef_b)
+    H.gn_apply(buf, Ct, None, gamma, beta, film, 1, 0.0, 0, H.RS_NONE, y_b, Ct, nimg, Hh, Ww, Ct, coef_b)
+    assert torch.equal(coef_a, coef_b) and torch.equal(y_a, y_b)
 
 
 @pytest.mark.parametrize("rs", [0, 1, 2])

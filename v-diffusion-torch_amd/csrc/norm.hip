@@ -131,8 +131,10 @@ __global__ void gn_stats_finalize_kernel(const float* part, int nimg, int chunks
 // tensor is the channel concatenation of up to two produced tensors, each with its own chunk size
 __global__ __launch_bounds__(256) void gn_stats_from_partials_kernel(const float* p1, int C1, int ch1, const float* p2, int C2,
                                                                      int ch2, int nimg, int G, long long HW, float eps,
-                                                                     float* stats) {
-    // one wave per (image, group): lanes stride over the group's (chunk, channel) partials, fixed-order butterfly in fp64
+                                                                     float* stats, const float* gamma, const float* beta,
+                                                                     const float* film, float* coef) {
+    // one wave per (image, group): lanes stride over the group's (chunk, channel) partials, fixed-order butterfly in fp64;
+    // with `coef` the same wave also writes the group's rows of the apply table (what gn_coef_kernel does from `stats`)
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (idx >= nimg * G) return;
     const int b = idx / G, g = idx % G, C = C1 + C2, cg = C / G;
@@ -151,13 +153,24 @@ __global__ __launch_bounds__(256) void gn_stats_from_partials_kernel(const float
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if (lane == 0) {
-        const double n = (double)cg * (double)HW;
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[2 * idx] = (float)mean;
-        stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    const double n = (double)cg * (double)HW;
+    const double mean_d = s1 / n;
+    double var = s2 / n - mean_d * mean_d;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (stats && lane == 0) { stats[2 * idx] = mean; stats[2 * idx + 1] = rstd; }
+    if (coef) {
+        for (int c = cbeg + lane; c < cbeg + cg; c += 64) {
+            float sc = rstd * gamma[c];
+            float of = beta[c] - mean * sc;
+            if (film) {
+                const float shift = film[(long long)b * 2 * C + c], scale = film[(long long)b * 2 * C + C + c];
+                sc *= (1.f + scale);
+                of = of * (1.f + scale) + shift;
+            }
+            float* o = coef + (long long)b * 4 * C + c;
+            o[0] = sc; o[C] = of; o[2 * C] = rstd; o[3 * C] = -mean * rstd;
+        }
     }
 }
 
@@ -538,7 +551,20 @@ extern "C" int vd_gn_stats_from_partials(const float* part1, int32_t C1, int32_t
     VD_REQUIRE(part1 && C1 > 0 && chunks1 > 0 && (C1 + C2) % G == 0, "vd_gn_stats_from_partials: bad arguments");
     VD_REQUIRE(C2 == 0 || (part2 && chunks2 > 0), "vd_gn_stats_from_partials: second source incomplete");
     hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3((nimg * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, part1, C1,
-                       chunks1, part2, C2, chunks2, nimg, G, (long long)HW, eps, stats);
+                       chunks1, part2, C2, chunks2, nimg, G, (long long)HW, eps, stats, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr);
+    VD_LAUNCH_CHECK("gn_stats_from_partials_kernel");
+    return 0;
+}
+
+extern "C" int vd_gn_coef_from_partials(const float* part1, int32_t C1, int32_t chunks1, const float* part2, int32_t C2,
+                                        int32_t chunks2, int32_t nimg, int32_t HW, int32_t G, float eps, const float* gamma,
+                                        const float* beta, const float* film, float* coef, void* stream) {
+    VD_REQUIRE(part1 && C1 > 0 && chunks1 > 0 && (C1 + C2) % G == 0, "vd_gn_coef_from_partials: bad arguments");
+    VD_REQUIRE(C2 == 0 || (part2 && chunks2 > 0), "vd_gn_coef_from_partials: second source incomplete");
+    VD_REQUIRE(gamma && beta && coef, "vd_gn_coef_from_partials: missing norm operands");
+    hipLaunchKernelGGL(gn_stats_from_partials_kernel, dim3((nimg * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, part1, C1,
+                       chunks1, part2, C2, chunks2, nimg, G, (long long)HW, eps, (float*)nullptr, gamma, beta, film, coef);
     VD_LAUNCH_CHECK("gn_stats_from_partials_kernel");
     return 0;
 }
@@ -551,7 +577,9 @@ extern "C" int vd_gn_apply(const float* x, int64_t ldx, const float* stats, cons
     VD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "vd_gn_apply: C/ld must be multiples of 4");
     VD_REQUIRE(resample != VD_RS_DOWN || (H % 2 == 0 && W % 2 == 0), "vd_gn_apply: odd size cannot be average-pooled");
     const int has_norm = gamma != nullptr;
-    if (has_norm) {
+    if (has_norm && !stats) {
+        VD_REQUIRE(coef != nullptr, "vd_gn_apply: neither statistics nor a coefficient table given");   // vd_gn_coef_from_partials ran
+    } else if (has_norm) {
         VD_REQUIRE(stats && beta && coef && C % G == 0, "vd_gn_apply: missing norm operands");
         hipLaunchKernelGGL(gn_coef_kernel, dim3((nimg * C + 255) / 256), dim3(256), 0, st, stats, gamma, beta, film, nimg, C,
                            G, coef);

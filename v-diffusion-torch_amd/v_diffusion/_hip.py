@@ -39,6 +39,7 @@ _SIGNATURES = {
     "vd_gemm_last_tile": (C.c_int, []),
     "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_pack_conv3x3": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
@@ -199,6 +200,12 @@ def gn_stats_from_partials(parts, nimg, HW, stats, G=32, eps=1e-6):
     (p1, c1, k1), (p2, c2, k2) = parts[0], (parts[1] if len(parts) > 1 else (None, 0, 0))
     _check(lib().vd_gn_stats_from_partials(ptr(p1), c1, k1, ptr(p2), c2, k2, nimg, HW, G, eps, ptr(stats), stream()),
            "vd_gn_stats_from_partials")
+
+
+def gn_coef_from_partials(parts, nimg, HW, gamma, beta, film, coef, G=32, eps=1e-6):
+    (p1, c1, k1), (p2, c2, k2) = parts[0], (parts[1] if len(parts) > 1 else (None, 0, 0))
+    _check(lib().vd_gn_coef_from_partials(ptr(p1), c1, k1, ptr(p2), c2, k2, nimg, HW, G, eps, ptr(gamma), ptr(beta), ptr(film),
+                                          ptr(coef), stream()), "vd_gn_coef_from_partials")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):

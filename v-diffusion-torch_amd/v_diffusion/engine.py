@@ -151,11 +151,18 @@ class UNetEngine:
     def _parts(part, C, HW):
         return None if part is None else [(part, C, HW // (H.last_row_tile() // 2))]
 
-    def _stats(self, x, x_parts, B, HW, C, stats):
+    def _norm(self, x, x_parts, gn, film, act, p_drop, seed, rs, y, B, Hh, Ww, C):
+        """y = resample(dropout(act(FiLM(GroupNorm(x))))); returns the [B][4][C] coefficient table the backward pass needs.
+        With producer partials the statistics never exist as a tensor: one tiny kernel goes from partials to the table."""
+        coef = self._new(x, B, 4, C)
+        stats = None
         if x_parts is not None:
-            H.gn_stats_from_partials(x_parts, B, HW, stats, GROUPS, EPS)
+            H.gn_coef_from_partials(x_parts, B, Hh * Ww, gn.weight, gn.bias, film, coef, GROUPS, EPS)
         else:
-            H.gn_stats(x, _ld(x), B, HW, C, stats, GROUPS, EPS)
+            stats = self._new(x, B, GROUPS, 2)
+            H.gn_stats(x, _ld(x), B, Hh * Ww, C, stats, GROUPS, EPS)
+        H.gn_apply(x, _ld(x), stats, gn.weight, gn.bias, film, act, p_drop, seed, rs, y, _ld(y), B, Hh, Ww, C, coef, GROUPS)
+        return coef
 
     def _pack_f(self, w, cin_p=None):
         cache = self.pack_cache
@@ -299,21 +306,16 @@ class UNetEngine:
         B, Hh, Ww, Cin, ldx = _chk(x)
         Cout, rs = blk.cout, blk.rs
         Ho, Wo = (Hh // 2, Ww // 2) if rs == H.RS_DOWN else ((Hh * 2, Ww * 2) if rs == H.RS_UP else (Hh, Ww))
-        stats1, coef1 = self._new(x, B, GROUPS, 2), self._new(x, B, 4, Cin)
-        self._stats(x, x_parts, B, Hh * Ww, Cin, stats1)
         a1 = self._new(x, B, Ho, Wo, Cin)
-        H.gn_apply(x, ldx, stats1, mod.norm1.weight, mod.norm1.bias, None, 1, 0.0, 0, rs, a1, Cin, B, Hh, Ww, Cin, coef1, GROUPS)
+        coef1 = self._norm(x, x_parts, mod.norm1, None, 1, 0.0, 0, rs, a1, B, Hh, Ww, Cin)
         h1 = self._new(x, B, Ho, Wo, Cout)
         ph = self._part(x, B, Ho * Wo, Cout)
         H.conv3x3(a1, Cin, self._pack_f(mod.conv1.weight), mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout, stats_part=ph)
         h1_parts = self._parts(ph, Cout, Ho * Wo)
         c2, fi = self.film_slot[prefix]
         film = films[c2][fi]                              # [B][2*Cout], contiguous slice of the group's batched GEMM output
-        stats2, coef2 = self._new(x, B, GROUPS, 2), self._new(x, B, 4, Cout)
-        self._stats(h1, h1_parts, B, Ho * Wo, Cout, stats2)
         a2 = self._new(x, B, Ho, Wo, Cout)
-        H.gn_apply(h1, Cout, stats2, mod.norm2.weight, mod.norm2.bias, film, 1, p_drop, seed, H.RS_NONE, a2, Cout, B, Ho, Wo, Cout,
-                   coef2, GROUPS)
+        coef2 = self._norm(h1, h1_parts, mod.norm2, film, 1, p_drop, seed, H.RS_NONE, a2, B, Ho, Wo, Cout)
         if rs != H.RS_NONE:
             xs = self._new(x, B, Ho, Wo, Cin)
             H.gn_apply(x, ldx, None, None, None, None, 0, 0.0, 0, rs, xs, Cin, B, Hh, Ww, Cin, None, GROUPS)
@@ -389,10 +391,8 @@ class UNetEngine:
         B, Hh, Ww, C, ldx = _chk(x)
         L, nh, hd = Hh * Ww, mod.num_heads, mod.head_dim
         hid = nh * hd
-        stats, coef = self._new(x, B, GROUPS, 2), self._new(x, B, 4, C)
-        self._stats(x, x_parts, B, L, C, stats)
         xn = self._new(x, B, Hh, Ww, C)
-        H.gn_apply(x, ldx, stats, mod.norm.weight, mod.norm.bias, None, 0, 0.0, 0, H.RS_NONE, xn, C, B, Hh, Ww, C, coef, GROUPS)
+        coef = self._norm(x, x_parts, mod.norm, None, 0, 0.0, 0, H.RS_NONE, xn, B, Hh, Ww, C)
         qkv = self._new(x, B, L, 3 * hid)
         H.gemm(xn, mod.proj_in.weight, qkv, B * L, 3 * hid, C, a_kind=H.ROW, b_kind=H.ROW, lda=C, ldb=C, ldc=3 * hid,
                bias=mod.proj_in.bias)
@@ -531,10 +531,8 @@ class UNetEngine:
         # out_conv: GN -> SiLU -> 3x3
         C0 = m.hid_channels * m.ch_multipliers[0]
         gn, conv = m.out_conv[0], m.out_conv[2]
-        stats, coef = self._new(h, B, GROUPS, 2), self._new(h, B, 4, C0)
-        self._stats(h, h_parts, B, H0 * W0, C0, stats)
         a = self._new(h, B, H0, W0, C0)
-        H.gn_apply(h, _ld(h), stats, gn.weight, gn.bias, None, 1, 0.0, 0, H.RS_NONE, a, C0, B, H0, W0, C0, coef, GROUPS)
+        coef = self._norm(h, h_parts, gn, None, 1, 0.0, 0, H.RS_NONE, a, B, H0, W0, C0)
         co = m.out_channels
         cop = (co + 3) // 4 * 4
         out = torch.zeros((B, H0, W0, cop), dtype=torch.float32, device=h.device)
