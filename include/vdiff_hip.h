@@ -108,6 +108,10 @@ int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t ldd
  * mirrored (dgrad).  Either output may be NULL.  Padding channels are zero-filled. */
 int vd_pack_conv3x3(const float* w_oihw, int32_t Cout_w, int32_t Cin_w,
                     float* wf, int32_t Cin_p, float* wd, int32_t Cout_p, void* stream);
+/* the same for many tensors in one launch.  items_dev: DEVICE table of n x 8 int64 {w_oihw, wf (or 0), wd (or 0), Cout_w,
+ * Cin_w, Cin_p, Cout_p, first_block}; tensor i owns blocks [first_block_i, first_block_{i+1}) of 256 elements each, enough
+ * for max(Cout_w*9*Cin_p, Cin_w*9*Cout_p); total_blocks = end of the last tensor. */
+int vd_pack_conv3x3_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm(32, C, eps) + SiLU + FiLM + dropout + resample
  * (nn.GroupNorm unet.py:28-30, nn.SiLU unet.py:25, FiLM unet.py:145-146, nn.Dropout unet.py:135,147,

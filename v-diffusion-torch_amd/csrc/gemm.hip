@@ -775,6 +775,39 @@ __global__ void pack_conv3x3_kernel(const float* w, int Cout_w, int Cin_w, float
     }
 }
 
+
+// all 3x3 kernels of a network in ONE launch (the per-tensor form costs ~110 launches of ~6 us per training step).
+// items: device table, 8 x int64 per tensor: {w, wf, wd, Cout, Cin, Cin_p, Cout_p, first block}; blocks of 256 elements.
+__global__ void pack_conv3x3_batched_kernel(const long long* items, int n) {
+    int lo = 0, hi = n - 1;                                  // last item whose first block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[8 * mid + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* it = items + 8 * lo;
+    const float* w = reinterpret_cast<const float*>(it[0]);
+    float* wf = reinterpret_cast<float*>(it[1]);
+    float* wd = reinterpret_cast<float*>(it[2]);
+    const int Cout_w = (int)it[3], Cin_w = (int)it[4], Cin_p = (int)it[5], Cout_p = (int)it[6];
+    const long long idx = ((long long)blockIdx.x - it[7]) * blockDim.x + threadIdx.x;
+    if (wf) {
+        const long long tot = (long long)Cout_w * 9 * Cin_p;
+        if (idx < tot) {
+            const int co = idx / (9 * Cin_p), rem = idx % (9 * Cin_p);
+            const int tap = rem / Cin_p, ci = rem % Cin_p;
+            wf[idx] = (ci < Cin_w) ? w[((long long)co * Cin_w + ci) * 9 + tap] : 0.f;
+        }
+    }
+    if (wd) {
+        const long long tot = (long long)Cin_w * 9 * Cout_p;
+        if (idx < tot) {
+            const int ci = idx / (9 * Cout_p), rem = idx % (9 * Cout_p);
+            const int tap = rem / Cout_p, co = rem % Cout_p;
+            wd[idx] = (co < Cout_w) ? w[((long long)co * Cin_w + ci) * 9 + (8 - tap)] : 0.f;
+        }
+    }
+}
+
 thread_local int g_last_tile = 0;
 thread_local int g_last_slabs = 1;     // slabs the last split-K launch really wrote
 
@@ -1041,5 +1074,13 @@ extern "C" int vd_pack_conv3x3(const float* w_oihw, int32_t Cout_w, int32_t Cin_
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout_w,
                        Cin_w, wf, Cin_p, wd, Cout_p);
     VD_LAUNCH_CHECK("pack_conv3x3_kernel");
+    return 0;
+}
+
+extern "C" int vd_pack_conv3x3_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream) {
+    VD_REQUIRE(items_dev && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "vd_pack_conv3x3_batched: bad table");
+    hipLaunchKernelGGL(pack_conv3x3_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(items_dev), n);
+    VD_LAUNCH_CHECK("pack_conv3x3_batched_kernel");
     return 0;
 }

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_pack_conv3x3": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "vd_pack_conv3x3_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_gn_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "vd_gn_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "vd_gn_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -241,6 +242,12 @@ def thin_wgrad_finish(g, Cout_w, Cin, Cin_w, dw, accumulate=False, colsum=None, 
 
 def pack_conv3x3(w, Cout_w, Cin_w, wf=None, Cin_p=0, wd=None, Cout_p=0):
     _check(lib().vd_pack_conv3x3(ptr(w), Cout_w, Cin_w, ptr(wf), Cin_p, ptr(wd), Cout_p, stream()), "vd_pack_conv3x3")
+
+
+def pack_conv3x3_batched(table, n, total_blocks):
+    """table: int64 device tensor [n][8], see vd_pack_conv3x3_batched"""
+    assert table.is_cuda and table.dtype == torch.int64 and table.is_contiguous()
+    _check(lib().vd_pack_conv3x3_batched(table.data_ptr(), n, total_blocks, stream()), "vd_pack_conv3x3_batched")
 
 
 def gn_stats(x, ldx, nimg, HW, Cc, stats, G=32, eps=1e-6):

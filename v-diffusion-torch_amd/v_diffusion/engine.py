@@ -131,6 +131,8 @@ class UNetEngine:
         # forward weight packs kept across calls while a sampler holds the weights fixed (set to {} by the sampling loop,
         # None otherwise: training repacks every step because the optimizer rewrites the weights)
         self.pack_cache = None
+        self._pack_state = None           # persistent buffers + device table of the batched weight pack
+        self._packed = None               # {id(weight): (wf, wd)} valid for the weights as of the last forward
 
     # ------------------------------------------------------------------------------------------ small helpers
     @staticmethod
@@ -164,7 +166,42 @@ class UNetEngine:
         H.gn_apply(x, _ld(x), stats, gn.weight, gn.bias, film, act, p_drop, seed, rs, y, _ld(y), B, Hh, Ww, C, coef, GROUPS)
         return coef
 
+    def _pack_all(self, need_d):
+        """Re-pack the 3x3 kernels of every residual block in ONE launch (vd_pack_conv3x3_batched) into persistent
+        buffers; returns {id(weight): (forward pack, dgrad pack or None)}.  The device table is rebuilt only when a
+        parameter's storage moved (load_state_dict keeps it, an EMA view swap does not)."""
+        ws = [c.weight for b in self.plan if b.res is not None for c in (b.res.conv1, b.res.conv2)]
+        key = tuple(w.data_ptr() for w in ws)
+        if self._pack_state is None:
+            self._pack_state = {}
+        st = self._pack_state.get(bool(need_d))          # training and inference keep separate tables / buffers
+        if st is None or st["key"] != key:
+            dev = ws[0].device
+            sizes = [w.numel() for w in ws]
+            if st is None or st["wf"].numel() != sum(sizes) or st["wf"].device != dev:
+                wf_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+                wd_all = None
+            else:
+                wf_all, wd_all = st["wf"], st["wd"]
+            if need_d and wd_all is None:
+                wd_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            rows, views, off, blk = [], {}, 0, 0
+            for w, n in zip(ws, sizes):
+                co, ci = w.shape[0], w.shape[1]
+                wf = wf_all[off: off + n].view(co, 9, ci)
+                wd = wd_all[off: off + n].view(ci, 9, co) if need_d else None
+                rows.append([w.data_ptr(), wf.data_ptr(), wd.data_ptr() if need_d else 0, co, ci, ci, co, blk])
+                views[id(w)] = (wf, wd)
+                off += n
+                blk += (n + 255) // 256
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            st = self._pack_state[bool(need_d)] = dict(key=key, wf=wf_all, wd=wd_all, table=table, n=len(ws), blocks=blk, views=views)
+        H.pack_conv3x3_batched(st["table"], st["n"], st["blocks"])
+        return st["views"]
+
     def _pack_f(self, w, cin_p=None):
+        if self._packed is not None and id(w) in self._packed:
+            return self._packed[id(w)][0]
         cache = self.pack_cache
         if cache is not None and id(w) in cache:
             return cache[id(w)]
@@ -177,6 +214,8 @@ class UNetEngine:
         return wf
 
     def _pack_d(self, w, cout_p=None):
+        if self._packed is not None and id(w) in self._packed and self._packed[id(w)][1] is not None:
+            return self._packed[id(w)][1]
         co, ci = w.shape[0], w.shape[1]
         cout_p = cout_p or co
         wd = self._new(w, ci, 9, cout_p)
@@ -461,6 +500,13 @@ class UNetEngine:
         assert Ci == m.in_channels and H0 % (1 << (self.levels - 1)) == 0 and W0 % (1 << (self.levels - 1)) == 0
         tape = {} if save else None
         x_nchw = x_nchw.to(torch.float32).contiguous()
+        cache = self.pack_cache
+        if cache is not None and "all" in cache:
+            self._packed = cache["all"]                  # a sampler holds the weights fixed: packed once per chain
+        else:
+            self._packed = self._pack_all(need_d=save)
+            if cache is not None:
+                cache["all"] = self._packed
         ta = self._embed_fwd(t, y, tape)
         films = self._film_fwd(ta, tape)
         p_drop = float(m.drop_rate) if training else 0.0
