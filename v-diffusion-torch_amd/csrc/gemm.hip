@@ -847,14 +847,14 @@ int choose_tile(long long M, long long Ncols, bool wgrad, long long zcount, int 
 
 // K tile of the kernel that will run.  The 128x128 LDS-DMA kernel exists with KT = 32 (64 KB LDS, 2 workgroups per CU)
 // and KT = 16 (32 KB LDS, ~106 VGPRs: 4 per CU): the deeper occupancy wins (+2-3 %) only when the launch has enough
-// workgroups to give every CU four of them for a long time; short launches keep the longer K tile.  `wide` = the caller
+// workgroups to give every CU four of them (>= 1024); short launches keep the longer K tile.  `wide` = the caller
 // (conv weight gradient with >= 64 Ki pixels) sized its split-K slabs for 4 workgroups per CU.
 inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk, bool wide) {
     static const char* force = getenv("VD_GEMM_KT");
     if (t != 0 || !use_dma(a)) return KT;
     if (force) return atoi(force) == 16 ? 16 : 32;
     if (splitk) return wide ? 16 : 32;
-    return nblocks >= 2048 ? 16 : 32;
+    return nblocks >= 1024 ? 16 : 32;           // 1024 workgroups = four per CU, all resident (measured: +0.7 % on the sampler)
 }
 
 // conv weight gradients with at least this many pixels (K of the GEMM) run the KT = 16 kernel, 4 workgroups per CU
