@@ -375,6 +375,10 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     __shared__ float red[TPB][8];
     __shared__ float chs[2][128];        // per-channel S1 (sum dz), S2 (sum dz*xhat) ; later k*S1, k*S2
     __shared__ float gm[2][32];
+    // 1024 threads x 8 pixels would need 64 registers of payload + temporaries > the 128 a 16-wave workgroup gets: the
+    // x_hat values of pixels 4..7 live in LDS instead (64 KB; scratch spills would go to HBM -- PMC showed +75 % traffic)
+    constexpr int NREG = (NPT == 8 && TPB == 1024) ? 4 : NPT;
+    __shared__ f32x4 xl[NPT - NREG > 0 ? NPT - NREG : 1][NPT - NREG > 0 ? TPB : 1];
     const ReduceArgs& p = f.a.r;
     const int b = blockIdx.y, c0 = blockIdx.x * f.CS, CS = f.CS, C = p.C;
     const int vecs = CS >> 2, rows = TPB / vecs, tid = threadIdx.x;
@@ -393,20 +397,22 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     const float* dimg = p.dy + (long long)b * HWo * p.lddy;
     const float* ximg = p.x + (long long)b * p.HW * p.ldx;
     const int vtot = C >> 2;
-    f32x4 xv[NPT], dz[NPT];
+    f32x4 xv[NREG], dz[NPT];
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int pix = r + i * rows;
-        xv[i] = a0 * 0.f; dz[i] = xv[i];
+        f32x4 xh = a0 * 0.f;
+        dz[i] = xh;
         if (act && pix < HW) {
             const f32x4 xin = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
             const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
             dz[i] = dz_of(p, dimg, pix, c4, xin, sc, of, vi);
-            xv[i] = xin * nr + nm;                          // keep x_hat: all the second half needs
+            xh = xin * nr + nm;                             // keep x_hat: all the second half needs
             a0 += dz[i];
-            a1 += dz[i] * xv[i];
+            a1 += dz[i] * xh;
         }
+        if (i < NREG) xv[i] = xh; else xl[i - NREG][tid] = xh;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[tid][j] = act ? a0[j] : 0.f; red[tid][4 + j] = act ? a1[j] : 0.f; }
@@ -470,7 +476,8 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     for (int i = 0; i < NPT; ++i) {
         const int pix = r + i * rows;
         if (pix >= HW) continue;
-        f32x4 d = q0 * dz[i] - q1 - xv[i] * q2;
+        const f32x4 xh = i < NREG ? xv[i < NREG ? i : 0] : xl[i < NREG ? 0 : i - NREG][tid];
+        f32x4 d = q0 * dz[i] - q1 - xh * q2;
         if (aimg) d += *reinterpret_cast<const f32x4*>(aimg + (long long)pix * f.a.ldadd + c4);
         float* o = oimg + (long long)pix * f.a.lddx + c4;
         if (f.a.accumulate_dx) d += *reinterpret_cast<const f32x4*>(o);
