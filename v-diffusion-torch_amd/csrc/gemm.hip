@@ -547,6 +547,11 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
 #pragma unroll
     for (int a = 0; a < MT; ++a) csum[a] = 0.f;
     const bool do_cs = (AK == VD_COL) && p.colsum != nullptr && tbx == 0 && (wave & 1) == 0;
+    // timing probe (VD_GEMM_PROBE bit 4, tests/probe/stamps.py): per-workgroup 100 MHz timestamps {start, main loop done,
+    // epilogue issued, stores drained} written through the colsum pointer
+    const bool dbg = (p.probe & 16) != 0;
+    unsigned long long ts0 = 0, ts2 = 0;
+    if (dbg) ts0 = __builtin_amdgcn_s_memrealtime();
 
     // fragment loads of sub-step s (8 k values): MT + NT LDS reads per wave
     auto load_frags = [&](const float* as, const float* bs, int s, f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
@@ -653,6 +658,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         }
     }
 
+    if (dbg) ts2 = __builtin_amdgcn_s_memrealtime();
     if (AK == VD_COL && do_cs) {
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
@@ -664,46 +670,56 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             }
         }
     }
+    // ---- epilogue.  D[row][col] of a 32x32 MFMA block: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Every output / residual access is a buffer instruction: descriptor = block base, per-lane 32-bit voffset computed ONCE
+    // per column block, the row walks in the SCALAR offset.  The wave shares its SIMD with three waves issuing MFMAs
+    // back to back, so every VALU instruction of the epilogue waits for a bubble (in-kernel stamps: the flat-pointer form,
+    // ~12 VALU per element for 64-bit addresses, took 36-50 us per workgroup = 8 % of a 3x3 conv launch and 40 % of a
+    // K = 256 GEMM).  Rows >= M fall outside num_records and are dropped by the hardware; invalid columns get voffset = OOB.
+    const int rows_valid = min(BM, p.M - m0);
+    const int ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4;
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(C + (long long)m0 * p.ldc + n0, rows_valid * ldc4);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R ? R + (long long)m0 * p.ldr + n0 : C, R ? rows_valid * ldr4 : 0);
+    const int row_lane = wm + (A2 ? 8 : 4) * lh;
+    const bool want_stats = !SPLITK && p.stats != nullptr, edge = rows_valid < BM;       // both uniform
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int ncol = wn + (B2 ? 2 * li + b : 32 * b + li);
         const int n = n0 + ncol;
         const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
-        if (!nok) continue;
-        const float bv = (!SPLITK && biasp) ? biasp[n] : 0.f;
+        const unsigned voc = nok ? (unsigned)(row_lane * ldc4 + ncol * 4) : OOB;
+        const unsigned vor = nok ? (unsigned)(row_lane * ldr4 + ncol * 4) : OOB;
+        const float bv = (!SPLITK && biasp && nok) ? biasp[n] : 0.f;
         float st1 = 0.f, st2 = 0.f;           // per-column sum / sum of squares of this wave's BM/2 output rows
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
-            // residual / accumulate operands of the whole 32x32 block are fetched BEFORE its first store: C may alias R
-            // (and is its own input when accumulating), so the compiler must otherwise serialise 16 load->store round trips
+            // residual / accumulate operands of the whole 32x32 block are fetched BEFORE its first store (C may alias R,
+            // and is its own input when accumulating)
             float addv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rt = (r & 3) + 8 * (r >> 2) + 4 * lh;              // row inside the 32x32 MFMA block
-                const int m = m0 + wm + (A2 ? 2 * rt + a : 32 * a + rt);
+                const int rs = A2 ? 2 * ((r & 3) + 8 * (r >> 2)) + a : 32 * a + (r & 3) + 8 * (r >> 2);   // uniform row part
                 float t = 0.f;
-                if (!SPLITK && m < p.M) {
-                    if (R) t = R[(long long)m * p.ldr + n];
-                    if (p.accumulate) t += C[(long long)m * p.ldc + n];
+                if (!SPLITK) {
+                    if (R) t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)vor, rs * ldr4, 0));
+                    if (p.accumulate) t += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)voc, rs * ldc4, 0));
                 }
                 addv[r] = t;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rt = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int m = m0 + wm + (A2 ? 2 * rt + a : 32 * a + rt);
-                if (m >= p.M) continue;
+                const int rs = A2 ? 2 * ((r & 3) + 8 * (r >> 2)) + a : 32 * a + (r & 3) + 8 * (r >> 2);
                 float v = acc[a][b][r];
                 if (!SPLITK) {
                     v = (v * p.alpha + bv) + addv[r];
-                    st1 += v; st2 += v * v;
+                    if (want_stats && (!edge || rs + row_lane < rows_valid)) { st1 += v; st2 += v * v; }
                 }
-                C[(long long)m * p.ldc + n] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, (int)voc, rs * ldc4, 0);
             }
         }
         // GroupNorm statistics of the tensor being written, for the norm that consumes it next (saves that norm's read
         // pass): the two lane halves hold complementary rows of the wave's BM/2-row slab, which lies inside one image
-        if (!SPLITK && p.stats) {
+        if (want_stats && nok) {
             st1 += __shfl_xor(st1, 32, 64);
             st2 += __shfl_xor(st2, 32, 64);
             const int mrow = m0 + wm;
@@ -713,6 +729,14 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                 o[0] = st1; o[p.N] = st2;
             }
         }
+    }
+    if (dbg && tid == 0) {
+        const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts4 = __builtin_amdgcn_s_memrealtime();
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + 4ULL * lin;
+        o[0] = ts0; o[1] = ts2; o[2] = ts3; o[3] = ts4;
     }
 }
 
@@ -816,7 +840,8 @@ bool use_dma(const GemmArgs& a) {
     if (legacy) return false;
     // 32-bit byte offsets inside one block tile must stay below the descriptor range
     const long long lim = 0x70000000LL / 4;
-    return 128LL * a.lda + 128 < lim && 128LL * a.ldb + 128 < lim && vd_aligned16(a.A) && vd_aligned16(a.B);
+    return 128LL * a.lda + 128 < lim && 128LL * a.ldb + 128 < lim && 128LL * a.ldc + 128 < lim && 128LL * a.ldr + 128 < lim &&
+           vd_aligned16(a.A) && vd_aligned16(a.B);
 }
 
 // ---- block-tile menu.  Rectangular tiles exist for channel counts that are not multiples of 128 (CelebA: 192, 576, 960,
@@ -917,7 +942,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.stats = d.stats; a.stats_hw = d.stats_hw;
     a.sBias = d.sBias;
     { static const char* e = getenv("VD_GEMM_PROBE"); a.probe = e ? atoi(e) : 0; }
-    VD_REQUIRE(!(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
+    VD_REQUIRE((a.probe & 16) || !(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
 
     const int tile = choose_tile(d.M, wgrad ? d.Cin : d.N, wgrad, (long long)batch * splitk, d.tile);
     const int tbm = TILES[tile].bm, tbn = TILES[tile].bn;
