@@ -691,6 +691,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         const unsigned vor = nok ? (unsigned)(row_lane * ldr4 + ncol * 4) : OOB;
         const float bv = (!SPLITK && biasp && nok) ? biasp[n] : 0.f;
         float st1 = 0.f, st2 = 0.f;           // per-column sum / sum of squares of this wave's BM/2 output rows
+        f32x2 st1p = {0.f, 0.f}, st2p = {0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             // residual / accumulate operands of the whole 32x32 block are fetched BEFORE its first store (C may alias R,
@@ -707,16 +708,29 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                 addv[r] = t;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rs = A2 ? 2 * ((r & 3) + 8 * (r >> 2)) + a : 32 * a + (r & 3) + 8 * (r >> 2);
-                float v = acc[a][b][r];
+            for (int r = 0; r < 16; r += 2) {
+                // two rows at a time in packed fp32 (v_pk_fma_f32 / v_pk_add_f32): half the VALU instructions
+                const int rs0 = A2 ? 2 * ((r & 3) + 8 * (r >> 2)) + a : 32 * a + (r & 3) + 8 * (r >> 2);
+                const int rs1 = A2 ? rs0 + 2 : rs0 + 1;                               // r + 1 stays inside the same group of four
+                f32x2 v = {acc[a][b][r], acc[a][b][r + 1]};
                 if (!SPLITK) {
-                    v = (v * p.alpha + bv) + addv[r];
-                    if (want_stats && (!edge || rs + row_lane < rows_valid)) { st1 += v; st2 += v * v; }
+                    const f32x2 al = {p.alpha, p.alpha}, bb = {bv, bv}, ad = {addv[r], addv[r + 1]};
+                    v = (v * al + bb) + ad;
+                    if (want_stats) {
+                        if (!edge) { st1p += v; st2p += v * v; }
+                        else {
+                            if (rs0 + row_lane < rows_valid) { st1 += v[0]; st2 += v[0] * v[0]; }
+                            if (rs1 + row_lane < rows_valid) { st1 += v[1]; st2 += v[1] * v[1]; }
+                        }
+                    }
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, (int)voc, rs * ldc4, 0);
+                const float v0 = v[0], v1 = v[1];       // (bit_cast straight from a vector element stores element 0 twice: hipcc 7.2)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), crs, (int)voc, rs0 * ldc4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), crs, (int)voc, rs1 * ldc4, 0);
             }
         }
+        st1 += st1p[0] + st1p[1];
+        st2 += st2p[0] + st2p[1];
         // GroupNorm statistics of the tensor being written, for the norm that consumes it next (saves that norm's read
         // pass): the two lane halves hold complementary rows of the wave's BM/2-row slab, which lies inside one image
         if (want_stats && nok) {
