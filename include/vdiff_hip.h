@@ -66,9 +66,10 @@ typedef struct vd_gemm_desc {
 /* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two
  * einsum contractions of attention (unet.py:57,61-63) and all of their autograd backward GEMMs */
 int vd_gemm(const vd_gemm_desc* d, void* stream);
-/* (KT*1000 + BM)*1000 + BN of the calling thread's last vd_gemm / vd_conv3x3* launch (profiling aid: names the kernel
- * instantiation gemm_dma_kernel<BM,BN,a_kind,b_kind,splitk,KT> the launch went to; KT = 0 means the register-staged
- * fallback gemm_kernel<BM,BN,a_kind,b_kind,splitk>) */
+/* ((TR*100 + KT)*1000 + BM)*1000 + BN of the calling thread's last vd_gemm / vd_conv3x3* launch (profiling aid: names the
+ * kernel instantiation gemm_dma_kernel<BM,BN,a_kind,b_kind,splitk,KT,TR> the launch went to; TR = 1: transposed-accumulator
+ * epilogue (launches without output statistics); KT = 0 means the register-staged fallback
+ * gemm_kernel<BM,BN,a_kind,b_kind,splitk>) */
 int vd_gemm_last_tile(void);
 
 /* 3x3 / stride 1 / pad 1 convolution, NHWC (replaces F.conv2d at modules.py:141-144 <- unet.py:121,125,217,232).

@@ -21,7 +21,7 @@ def timed(key, flops, fn):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(); e1.record()
     t = H.lib().vd_gemm_last_tile()
-    REC.append((key + f" tile={(t // 1000) % 1000}x{t % 1000}/kt{t // 1000000}", flops, e0, e1))
+    REC.append((key + f" tile={(t // 1000) % 1000}x{t % 1000}/kt{(t // 1000000) % 100}{'T' if t // 100000000 else ''}", flops, e0, e1))
 
 
 def gemm(A, B, Cm, M, N, K, **kw):

@@ -364,7 +364,11 @@ __device__ __forceinline__ int row_swz_t(int row, int chunk) { return row * KT +
 
 // KT = K tile.  128x128 tiles use KT = 16: 32 KB of LDS per workgroup -> 4 workgroups (4 waves per SIMD) per CU, which
 // fills the MFMA issue slots a barrier-parked wave leaves empty (PMC: 2 waves/SIMD left the matrix pipe 14.5 % idle).
-template <int BM, int BN, int AK, int BK, bool SPLITK, int KT>
+// TR: the MFMA operands are swapped (D = B.A^T), so a lane holds FOUR CONSECUTIVE COLUMNS of one output row per register
+// quad instead of four consecutive rows of one column: the epilogue writes (and reads residuals) with 16 dwordx4 buffer
+// instructions per wave instead of 64 dword ones.  Used by every launch that does not ask for output statistics (their
+// per-column sums need a column per lane) when N, ldc, ldr are multiples of 4.
+template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR>
 __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * KT];
     constexpr int MT = BM / 64, NT = BN / 64;
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     // ds_read_b64 and block a takes element a, i.e. MFMA block a owns the interleaved rows {2i + a} instead of
     // {32a + i}.  Halves the LDS instructions of the weight-gradient kernels; only the output row/column map changes.
     constexpr bool A2 = (AK == VD_COL) && (MT == 2);
-    constexpr bool B2 = (BK != VD_ROW) && (NT == 2);
+    constexpr bool B2 = !TR && (BK != VD_ROW) && (NT == 2);      // (TR needs the columns of a block contiguous)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -600,7 +604,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+                    acc[a][b] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(fb[b][j], fa[a][j], acc[a][b], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
     };
 
     // software pipeline over the KT/8 sub-steps: the fragments of sub-step s+1 are requested BEFORE the MFMAs of
@@ -680,6 +685,44 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     const int ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4;
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(C + (long long)m0 * p.ldc + n0, rows_valid * ldc4);
     const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R ? R + (long long)m0 * p.ldr + n0 : C, R ? rows_valid * ldr4 : 0);
+    if (TR) {
+        // lane (li, lh), register quad q: row = block row li, columns 8q + 4lh .. +3 of the block
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 al4 = {p.alpha, p.alpha, p.alpha, p.alpha};
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int rowl = wm + (A2 ? 2 * li + a : 32 * a + li);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int ncol = wn + 32 * b + 4 * lh;                      // first column of this lane's quads (+ 8q)
+                const int n = n0 + ncol;
+                f32x4 bias4[4], add4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol + 8 * q < p.Cin) : (n + 8 * q < p.N);
+                    const unsigned voc = nok ? (unsigned)(rowl * ldc4 + (ncol + 8 * q) * 4) : OOB;
+                    const unsigned vor = nok ? (unsigned)(rowl * ldr4 + (ncol + 8 * q) * 4) : OOB;
+                    bias4[q] = (!SPLITK && biasp && nok) ? *reinterpret_cast<const f32x4*>(biasp + n + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (!SPLITK) {
+                        if (R) t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0));
+                        if (p.accumulate) t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (int)voc, 0, 0));
+                    }
+                    add4[q] = t;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol + 8 * q < p.Cin) : (n + 8 * q < p.N);
+                    const unsigned voc = nok ? (unsigned)(rowl * ldc4 + (ncol + 8 * q) * 4) : OOB;
+                    f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                    if (!SPLITK) v = (v * al4 + bias4[q]) + add4[q];
+                    const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(u, crs, (int)voc, 0, 0);
+                }
+            }
+        }
+        return;
+    }
     const int row_lane = wm + (A2 ? 8 : 4) * lh;
     const bool want_stats = !SPLITK && p.stats != nullptr, edge = rows_valid < BM;       // both uniform
 #pragma unroll
@@ -900,14 +943,30 @@ inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk, b
 // (measured: +2-3 % at 128 Ki pixels, -0..20 % at 32 Ki and below)
 constexpr long long WGRAD_WIDE_PIXELS = 65536;
 
+// transposed-accumulator epilogue (dwordx4 stores): whenever the launch does not want output statistics and every row is
+// 16-byte addressable
+bool use_tr(const GemmArgs& a, bool wgrad) {
+    static const char* env = getenv("VD_GEMM_TR");               // A/B switch: 0 disables
+    if (env && atoi(env) == 0) return false;
+    if (a.stats) return false;
+    const long long ncols = wgrad ? a.Cin : a.N;
+    if (ncols % 4 || a.ldc % 4 || !vd_aligned16(a.C)) return false;
+    if (a.R && (a.ldr % 4 || !vd_aligned16(a.R) || a.sRb % 4 || a.sRh % 4)) return false;
+    if (a.bias && (!vd_aligned16(a.bias) || a.sBias % 4)) return false;
+    return a.sCb % 4 == 0 && a.sCh % 4 == 0 && a.slab_stride % 4 == 0;
+}
+
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     constexpr bool has16 = BM == 128 && BN == 128;       // the only tile with a KT = 16 instantiation
     const bool k16 = has16 && ktile == 16;
-    g_last_tile = ((use_dma(a) ? (k16 ? 16 : 32) : 0) * 1000 + BM) * 1000 + BN;
+    const bool tr = use_dma(a) && use_tr(a, BK == VD_IM2COL);
+    g_last_tile = ((((tr ? 1 : 0) * 100 + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
-    else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32)>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32>), grid, dim3(256), 0, st, a);
+    else if (k16 && tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true>), grid, dim3(256), 0, st, a);
+    else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false>), grid, dim3(256), 0, st, a);
+    else if (tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, false>), grid, dim3(256), 0, st, a);
 }
 
 template <int AK, int BK, bool SPLITK>

@@ -126,7 +126,8 @@ _ws_cache = {}
 
 # When set to a list, the matmul-shaped wrappers append (kernel_name, flops, start_event, end_event) per launch
 # (bench.py uses it for the live roofline figure; events sit on the stream the kernels are launched on).  Names are the
-# rocprofv3 kernel names: gemm_dma_kernel<BM, BN, a_kind, b_kind, splitk, KT> with kinds 0 = ROW, 1 = COL, 2 = IM2COL.
+# rocprofv3 kernel names: gemm_dma_kernel<BM, BN, a_kind, b_kind, splitk, KT, TR> with kinds 0 = ROW, 1 = COL, 2 = IM2COL
+# (TR = transposed-accumulator epilogue, taken by launches without output statistics).
 PROFILE = None
 _KIND = {0: "ROW", 1: "COL", 2: "IM2COL"}
 
@@ -145,10 +146,10 @@ class _Timed:
         if PROFILE is not None and exc[0] is None:
             self.e1.record()
             t = lib().vd_gemm_last_tile()
-            kt, bm, bn = t // 1000000, (t // 1000) % 1000, t % 1000
-            name = self.name.format(tile=f"{bm}, {bn}", kt=kt)
+            tr, kt, bm, bn = t // 100000000, (t // 1000000) % 100, (t // 1000) % 1000, t % 1000
+            name = self.name.format(tile=f"{bm}, {bn}", kt=f"{kt}, {'true' if tr else 'false'}")
             if kt == 0:
-                name = name.replace("gemm_dma_kernel", "gemm_kernel").replace(", 0>", ">")
+                name = name.replace("gemm_dma_kernel", "gemm_kernel").replace(", 0, false>", ">")
             PROFILE.append((name, self.flops, self.e0, self.e1))
 
 
