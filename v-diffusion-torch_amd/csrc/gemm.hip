@@ -37,6 +37,7 @@ struct GemmArgs {
     int probe;                                // timing experiments only (VD_GEMM_PROBE): bit0/bit1 drop the A/B tile loads
     float* stats; int stats_hw;               // GroupNorm partials of the OUTPUT: [img][chunk][2][N], chunk = BM/2 output rows
     long long sBias;                          // bias offset per batch entry zb
+    int lgW, lgHW;                            // log2 of W and H*W when both are powers of two, else -1 (shift/mask instead of divisions)
 };
 
 __device__ __forceinline__ int row_swz(int row, int chunk) { return row * KT + ((chunk ^ ((row >> 1) & 7)) << 2); }
@@ -357,6 +358,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 
 // k-contiguous LDS image: [row][KT] floats, 16-byte chunk index XOR-swizzled so that a ds_read_b128 of 32 consecutive
 // rows at one chunk is bank-conflict free (KT = 32: 8 chunks/row, swizzle (row>>1)&7; KT = 16: 4 chunks/row, (row>>2)&3)
+
+// pixel index -> (y, x) inside its image; shifts when the geometry is a power of two (every shipped config), the divisions
+// otherwise.  Prologue VALU instructions compete with the MFMA stream of the co-resident workgroups for issue slots.
+__device__ __forceinline__ void pix_yx(const GemmArgs& p, int pix, int& y, int& x) {
+    if (p.lgW >= 0) { const int rem = pix & ((1 << p.lgHW) - 1); y = rem >> p.lgW; x = rem & ((1 << p.lgW) - 1); }
+    else { const int rem = pix % (p.H * p.W); y = rem / p.W; x = rem % p.W; }
+}
 template <int KT>
 __device__ __forceinline__ int swz_of(int row) { return KT == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 template <int KT>
@@ -446,20 +454,20 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         const int q = j * 4 + wave;
         if (AK == VD_COL) {
             const int kk = q * A_RPP + lane / A_LPR, cm = (lane % A_LPR) * 4;
-            voA[j] = (m0 + cm < p.M) ? (unsigned)(((long long)kk * p.lda + cm) * 4) : OOB;
+            voA[j] = (m0 + cm < p.M) ? (unsigned)(kk * (int)p.lda + cm) * 4u : OOB;
             kcA[j] = kk; mkA[j] = 0;
         } else {
             const int row = q * RRPP + lane / RLPR;
             const int c = (lane % RLPR) ^ swz_of<KT>(row);
             const int m = m0 + row;
             kcA[j] = c * 4;
-            voA[j] = (m < p.M) ? (unsigned)(((long long)row * p.lda + c * 4) * 4) : OOB;
+            voA[j] = (m < p.M) ? (unsigned)(row * (int)p.lda + c * 4) * 4u : OOB;      // < 2^31 by use_dma()
             unsigned mk = 0;
             if (AK == VD_IM2COL) {
-                const int rem = m % (p.H * p.W), y = rem / p.W, x = rem % p.W;
-#pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    if ((unsigned)(y + t / 3 - 1) < (unsigned)p.H && (unsigned)(x + t % 3 - 1) < (unsigned)p.W) mk |= 1u << t;
+                int y, x;
+                pix_yx(p, m, y, x);
+                const unsigned xm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);          // taps dx = -1, 0, +1 inside the row
+                mk = (y > 0 ? xm : 0u) | (xm << 3) | (y < p.H - 1 ? xm << 6 : 0u);             // bit t = tap t inside the image
             }
             mkA[j] = mk;
         }
@@ -471,18 +479,15 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             const int row = q * RRPP + lane / RLPR;
             const int c = (lane % RLPR) ^ swz_of<KT>(row);
             kcB[j] = c * 4;
-            voB[j] = (n0 + row < p.N) ? (unsigned)(((long long)row * p.ldb + c * 4) * 4) : OOB;
+            voB[j] = (n0 + row < p.N) ? (unsigned)(row * (int)p.ldb + c * 4) * 4u : OOB;
             by[j] = bx[j] = 0;
         } else {
             const int kk = q * B_RPP + lane / B_LPR, cn = (lane % B_LPR) * 4;
             kcB[j] = kk;
             const bool ok = (BK == VD_IM2COL) ? (ci0 + cn < p.Cin) : (n0 + cn < p.N);
-            voB[j] = ok ? (unsigned)(((long long)kk * p.ldb + cn) * 4) : OOB;
-            if (BK == VD_IM2COL) {
-                const int k = kt_begin * KT + kk;
-                const int rem = k % (p.H * p.W);
-                by[j] = rem / p.W; bx[j] = rem % p.W;
-            } else by[j] = bx[j] = 0;
+            voB[j] = ok ? (unsigned)(kk * (int)p.ldb + cn) * 4u : OOB;
+            if (BK == VD_IM2COL) pix_yx(p, kt_begin * KT + kk, by[j], bx[j]);
+            else by[j] = bx[j] = 0;
         }
     }
     // block-constant parts of the source addresses
@@ -664,6 +669,16 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     }
 
     if (dbg) ts2 = __builtin_amdgcn_s_memrealtime();
+    auto stamp_end = [&]() {
+        if (dbg && tid == 0) {
+            const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long ts4 = __builtin_amdgcn_s_memrealtime();
+            const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + 4ULL * lin;
+            o[0] = ts0; o[1] = ts2; o[2] = ts3; o[3] = ts4;
+        }
+    };
     if (AK == VD_COL && do_cs) {
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
@@ -721,6 +736,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                 }
             }
         }
+        stamp_end();
         return;
     }
     const int row_lane = wm + (A2 ? 8 : 4) * lh;
@@ -787,14 +803,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             }
         }
     }
-    if (dbg && tid == 0) {
-        const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long ts4 = __builtin_amdgcn_s_memrealtime();
-        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.colsum) + 4ULL * lin;
-        o[0] = ts0; o[1] = ts2; o[2] = ts3; o[3] = ts4;
-    }
+    stamp_end();
 }
 
 // out (+)= sum over slabs; optional OIHW transposition for the conv weight gradient
@@ -1014,6 +1023,10 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     a.colsum = d.colsum; a.colsum_accumulate = d.colsum_accumulate;
     a.stats = d.stats; a.stats_hw = d.stats_hw;
     a.sBias = d.sBias;
+    a.lgW = a.lgHW = -1;
+    if ((conv || wgrad) && (d.W & (d.W - 1)) == 0 && ((d.H * d.W) & (d.H * d.W - 1)) == 0) {
+        a.lgW = __builtin_ctz((unsigned)d.W); a.lgHW = __builtin_ctz((unsigned)(d.H * d.W));
+    }
     { static const char* e = getenv("VD_GEMM_PROBE"); a.probe = e ? atoi(e) : 0; }
     VD_REQUIRE((a.probe & 16) || !(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
 
