@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     // ds_read_b64 and block a takes element a, i.e. MFMA block a owns the interleaved rows {2i + a} instead of
     // {32a + i}.  Halves the LDS instructions of the weight-gradient kernels; only the output row/column map changes.
     constexpr bool A2 = (AK == VD_COL) && (MT == 2);
-    constexpr bool B2 = !TR && (BK != VD_ROW) && (NT == 2);      // (TR needs the columns of a block contiguous)
+    constexpr bool B2 = (BK != VD_ROW) && (NT == 2);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -525,6 +525,28 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             } else { boff = (long long)kt * KT * p.ldb + tapoffB; kwidth = p.K - kt * KT; }
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(Bblk + boff, p.probe & 2 ? 0 : (int)OOB);
             const int dy = tapN / 3 - 1, dx = tapN % 3 - 1;
+            if (BK == VD_IM2COL && p.lgW >= 0) {
+                // power-of-two images: a piece holds B_RPP whole pixels (B_LPR lanes each), so the padding / K-range test is
+                // done ONCE PER PIXEL ON THE SCALAR UNIT and applied with a single v_cndmask per piece through a lane mask
+                // (the per-lane coordinate bookkeeping below costs ~10 VALU per piece, and every VALU instruction of this
+                // loop competes with the MFMA stream of the co-resident workgroups for an issue slot)
+#pragma unroll
+                for (int j = 0; j < BIT; ++j) {
+                    const int k0 = kt * KT + (j * 4 + wave) * B_RPP;                 // first pixel of the piece (uniform)
+                    unsigned long long lanes = 0;
+#pragma unroll
+                    for (int u = 0; u < B_RPP; ++u) {
+                        const int k = k0 + u;
+                        const int rem = k & ((1 << p.lgHW) - 1), y = (rem >> p.lgW) + dy, x = (rem & ((1 << p.lgW) - 1)) + dx;
+                        const bool ok = k < p.K && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                        lanes |= ok ? (((B_LPR == 64 ? 0ull : (1ull << (B_LPR & 63))) - 1ull) << (u * (B_LPR & 63))) : 0ull;
+                    }
+                    unsigned vo;
+                    const unsigned oob = OOB;
+                    asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(vo) : "v"(oob), "v"(voB[j]), "s"(lanes));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(bs + (j * 4 + wave) * 256), 16, (int)vo, 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < BIT; ++j) {
                 unsigned vo = voB[j];
@@ -600,6 +622,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     };
     auto mfma_group = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
         if (AK == VD_COL && do_cs) {
+            asm volatile("" ::: "memory");      // keep this a branch: if-converted, every wave of the launch ran the adds
 #pragma unroll
             for (int a = 0; a < MT; ++a) csum[a] += (fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3]);
         }
@@ -701,39 +724,45 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     const __amdgpu_buffer_rsrc_t crs = make_rsrc(C + (long long)m0 * p.ldc + n0, rows_valid * ldc4);
     const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R ? R + (long long)m0 * p.ldr + n0 : C, R ? rows_valid * ldr4 : 0);
     if (TR) {
-        // lane (li, lh), register quad q: row = block row li, columns 8q + 4lh .. +3 of the block
+        // lane (li, lh): row = block row li; register quad q of block b holds columns 8q + 4lh .. +3 of that block.  With
+        // interleaved column ownership (B2: block b owns columns 2i + b) the four consecutive columns 16q + 8lh + 4h .. +3 of
+        // the wave's 64 are {block 0, block 1} x registers {4q + 2h, 4q + 2h + 1}.  Either way 8 quads per row block.
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const f32x4 al4 = {p.alpha, p.alpha, p.alpha, p.alpha};
+        constexpr int NQ = 4 * NT;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int rowl = wm + (A2 ? 2 * li + a : 32 * a + li);
+            f32x4 bias4[NQ], add4[NQ];
+            unsigned vocs[NQ];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int ncol = wn + 32 * b + 4 * lh;                      // first column of this lane's quads (+ 8q)
+            for (int e = 0; e < NQ; ++e) {
+                const int ncol = B2 ? wn + 16 * (e >> 1) + 8 * lh + 4 * (e & 1) : wn + 32 * (e >> 2) + 8 * (e & 3) + 4 * lh;
                 const int n = n0 + ncol;
-                f32x4 bias4[4], add4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol + 8 * q < p.Cin) : (n + 8 * q < p.N);
-                    const unsigned voc = nok ? (unsigned)(rowl * ldc4 + (ncol + 8 * q) * 4) : OOB;
-                    const unsigned vor = nok ? (unsigned)(rowl * ldr4 + (ncol + 8 * q) * 4) : OOB;
-                    bias4[q] = (!SPLITK && biasp && nok) ? *reinterpret_cast<const f32x4*>(biasp + n + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                    if (!SPLITK) {
-                        if (R) t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0));
-                        if (p.accumulate) t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (int)voc, 0, 0));
-                    }
-                    add4[q] = t;
+                const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
+                vocs[e] = nok ? (unsigned)(rowl * ldc4 + ncol * 4) : OOB;
+                const unsigned vor = nok ? (unsigned)(rowl * ldr4 + ncol * 4) : OOB;
+                bias4[e] = (!SPLITK && biasp && nok) ? *reinterpret_cast<const f32x4*>(biasp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (!SPLITK) {
+                    if (R) t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0));
+                    if (p.accumulate) t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (int)vocs[e], 0, 0));
                 }
+                add4[e] = t;
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol + 8 * q < p.Cin) : (n + 8 * q < p.N);
-                    const unsigned voc = nok ? (unsigned)(rowl * ldc4 + (ncol + 8 * q) * 4) : OOB;
-                    f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                    if (!SPLITK) v = (v * al4 + bias4[q]) + add4[q];
-                    const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(u, crs, (int)voc, 0, 0);
+            for (int e = 0; e < NQ; ++e) {
+                f32x4 v;
+                if (B2) {
+                    const int r0 = 4 * (e >> 1) + 2 * (e & 1);
+                    v = f32x4{acc[a][0][r0], acc[a][NT - 1][r0], acc[a][0][r0 + 1], acc[a][NT - 1][r0 + 1]};
+                } else {
+                    const int b = e >> 2, q = e & 3;
+                    v = f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
                 }
+                if (!SPLITK) v = (v * al4 + bias4[e]) + add4[e];
+                const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(u, crs, (int)vocs[e], 0, 0);
             }
         }
         stamp_end();
