@@ -34,7 +34,8 @@ struct GemmArgs {
     int kt_total, kt_per_split;
     long long slab_stride;
     float* colsum; int colsum_accumulate;     // COL-kind A only: colsum[m] (+)= sum_k A[k][m]  (bias gradients ride along)
-    int probe;                                // timing experiments only (VD_GEMM_PROBE): bit0/bit1 drop the A/B tile loads
+    int probe;                                // timing experiments only (VD_GEMM_PROBE): bit0/bit1 drop the A/B tile loads, bit2 the
+                                              // barrier, bit4 = phase timestamps through `colsum`, bit5 = loop-phase cycles through `stats`
     float* stats; int stats_hw;               // GroupNorm partials of the OUTPUT: [img][chunk][2][N], chunk = BM/2 output rows
     long long sBias;                          // bias offset per batch entry zb
     int lgW, lgHW;                            // log2 of W and H*W when both are powers of two, else -1 (shift/mask instead of divisions)
@@ -681,6 +682,25 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                 compute(buf);
                 buf ^= 1;
             }
+        } else if (p.probe & 32) {      // timing probe: core-clock cycles this wave spends issuing DMA / computing / waiting
+            unsigned long long t_dma = 0, t_cmp = 0, t_wait = 0;
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+                if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
+                const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+                compute(buf);
+                const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+                t_dma += c1 - c0; t_cmp += c2 - c1; t_wait += c3 - c2;
+                buf ^= 1;
+            }
+            if (lane == 0 && wave == 0) {
+                const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats) + 4ULL * lin;        // (probe: through `stats`)
+                o[0] = t_dma; o[1] = t_cmp; o[2] = t_wait; o[3] = (unsigned long long)(kt_end - kt_begin);
+            }
         } else
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
@@ -769,7 +789,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         return;
     }
     const int row_lane = wm + (A2 ? 8 : 4) * lh;
-    const bool want_stats = !SPLITK && p.stats != nullptr, edge = rows_valid < BM;       // both uniform
+    const bool want_stats = !SPLITK && p.stats != nullptr && !(p.probe & 32), edge = rows_valid < BM;       // both uniform
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int ncol = wn + (B2 ? 2 * li + b : 32 * b + li);
@@ -986,7 +1006,7 @@ constexpr long long WGRAD_WIDE_PIXELS = 65536;
 bool use_tr(const GemmArgs& a, bool wgrad) {
     static const char* env = getenv("VD_GEMM_TR");               // A/B switch: 0 disables
     if (env && atoi(env) == 0) return false;
-    if (a.stats) return false;
+    if (a.stats && !(a.probe & 32)) return false;
     const long long ncols = wgrad ? a.Cin : a.N;
     if (ncols % 4 || a.ldc % 4 || !vd_aligned16(a.C)) return false;
     if (a.R && (a.ldr % 4 || !vd_aligned16(a.R) || a.sRb % 4 || a.sRh % 4)) return false;
@@ -1064,7 +1084,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     const long long nm = (d.M + tbm - 1) / tbm;
     const long long nn = wgrad ? 9LL * ((d.Cin + tbn - 1) / tbn) : (d.N + tbn - 1) / tbn;
     VD_REQUIRE(nm <= 65535, "vd_gemm: too many row tiles (%lld)", nm);
-    if (d.stats) {
+    if (d.stats && !(a.probe & 32)) {
         VD_REQUIRE(batch == 1 && splitk == 1 && !wgrad && bk == VD_ROW && ak != VD_COL, "vd_gemm: output statistics need a plain forward launch");
         VD_REQUIRE(d.stats_hw > 0 && d.stats_hw % (tbm / 2) == 0 && d.M % d.stats_hw == 0,
                    "vd_gemm: output statistics need H*W (%d) to be a multiple of half the row tile (%d)", d.stats_hw, tbm / 2);
@@ -1083,7 +1103,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
                    "vd_gemm: split-K workspace too small");
         a.C = d.ws; a.ldc = d.N;
         float* cpart = d.ws + used * a.slab_stride;          // per-slab bias-gradient partials live behind the slabs
-        if (d.colsum) a.colsum = cpart;
+        if (d.colsum && !(a.probe & 16)) a.colsum = cpart;      // (probe builds write timestamps through colsum)
         dim3 grid(nn, nm, used);
         if (ak == VD_COL && bk == VD_COL) launch_tile<VD_COL, VD_COL>(tile, true, a, grid, st, ktile);
         else if (ak == VD_COL && bk == VD_IM2COL) launch_tile<VD_COL, VD_IM2COL>(tile, true, a, grid, st, ktile);
@@ -1091,7 +1111,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
         else if (ak == VD_ROW && bk == VD_COL) launch_tile<VD_ROW, VD_COL>(tile, true, a, grid, st, ktile);
         else VD_REQUIRE(false, "vd_gemm: split-K not built for kinds (%d,%d)", ak, bk);
         VD_LAUNCH_CHECK("gemm_kernel(splitk)");
-        if (!wgrad) {   // plain reduce here; the conv wgrad caller reduces with the OIHW transposition itself
+        if (!wgrad && !(a.probe & 16)) {   // plain reduce here; the conv wgrad caller reduces with the OIHW transposition itself
             const long long tot = (long long)d.M * d.N;
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, d.ws, used, a.slab_stride,
                                d.M, d.N, final_C, d.ldc, d.accumulate, d.alpha, cpart, d.colsum, d.colsum_accumulate);
