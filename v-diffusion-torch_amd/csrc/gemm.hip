@@ -496,9 +496,13 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     const float* Bblk = (BK == VD_ROW) ? B + (long long)n0 * p.ldb : ((BK == VD_COL) ? B + n0 : B + ci0);
     const long long tapoffB = (BK == VD_IM2COL) ? (long long)((tapN / 3 - 1) * p.W + (tapN % 3 - 1)) * p.ldb : 0;
 
-    auto dma_tiles = [&](int kt, int buf) {
-        float* as = smem + buf * (BM * KT);
-        float* bs = smem + 2 * BM * KT + buf * (BN * KT);
+    // The per-tile work is split in two: prep_tiles() does all the address / padding arithmetic of a K tile (scalar and
+    // vector ALU only, no memory effect) into a handful of registers, issue_tiles() is just the (BM+BN)/32 DMA instructions.
+    // prep(t+2) is called from INSIDE compute(t), so its ~55 instructions issue in the shadow of this wave's own MFMAs: a
+    // wave that spends 40 % of every tile in a serial SALU chain in front of its MFMAs (loop-phase probe, VD_GEMM_PROBE=32)
+    // leaves the matrix pipe idle whenever its three neighbours do the same.
+    struct Prep { const float* pA; const float* pB; unsigned vA[AIT], vB[BIT]; };   // (bases, not descriptors: the resource type cannot be a field)
+    auto prep_tiles = [&](int kt, Prep& P) {
         // ------------------------------------------------ A
         {
             const int tap = tapA, c0 = ccA * KT;
@@ -507,13 +511,13 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             if (AK == VD_IM2COL) { aoff = (long long)((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.lda + c0; kwidth = p.Cin - c0; }
             else if (AK == VD_ROW) { aoff = (long long)kt * KT; kwidth = p.K - kt * KT; }
             else { aoff = (long long)kt * KT * p.lda; kwidth = p.K - kt * KT; }
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Ablk + aoff, p.probe & 1 ? 0 : (int)OOB);   // probe: timing-only build knob
+            P.pA = Ablk + aoff;
 #pragma unroll
             for (int j = 0; j < AIT; ++j) {
                 unsigned vo = voA[j];
                 if (kcA[j] >= kwidth) vo = OOB;
                 if (AK == VD_IM2COL && !((mkA[j] >> tap) & 1u)) vo = OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(as + (j * 4 + wave) * 256), 16, (int)vo, 0, 0, 0);
+                P.vA[j] = vo;
             }
         }
         // ------------------------------------------------ B
@@ -524,13 +528,11 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                 if (AK == VD_IM2COL) { boff = (long long)tapA * p.Cin + ccA * KT; kwidth = p.Cin - ccA * KT; }
                 else { boff = (long long)kt * KT; kwidth = p.K - kt * KT; }
             } else { boff = (long long)kt * KT * p.ldb + tapoffB; kwidth = p.K - kt * KT; }
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(Bblk + boff, p.probe & 2 ? 0 : (int)OOB);
+            P.pB = Bblk + boff;
             const int dy = tapN / 3 - 1, dx = tapN % 3 - 1;
             if (BK == VD_IM2COL && p.lgW >= 0) {
                 // power-of-two images: a piece holds B_RPP whole pixels (B_LPR lanes each), so the padding / K-range test is
                 // done ONCE PER PIXEL ON THE SCALAR UNIT and applied with a single v_cndmask per piece through a lane mask
-                // (the per-lane coordinate bookkeeping below costs ~10 VALU per piece, and every VALU instruction of this
-                // loop competes with the MFMA stream of the co-resident workgroups for an issue slot)
 #pragma unroll
                 for (int j = 0; j < BIT; ++j) {
                     const int k0 = kt * KT + (j * 4 + wave) * B_RPP;                 // first pixel of the piece (uniform)
@@ -544,8 +546,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                     }
                     unsigned vo;
                     const unsigned oob = OOB;
-                    asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(vo) : "v"(oob), "v"(voB[j]), "s"(lanes));
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(bs + (j * 4 + wave) * 256), 16, (int)vo, 0, 0, 0);
+                    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(vo) : "v"(oob), "v"(voB[j]), "s"(lanes));
+                    P.vB[j] = vo;
                 }
             } else
 #pragma unroll
@@ -559,10 +561,22 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
                     while (ny >= p.H) ny -= p.H;
                     bx[j] = nx; by[j] = ny;
                 }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(bs + (j * 4 + wave) * 256), 16, (int)vo, 0, 0, 0);
+                P.vB[j] = vo;
             }
         }
         if (AK == VD_IM2COL) { if (++tapA == 9) { tapA = 0; ++ccA; } }
+    };
+    auto issue_tiles = [&](int buf, const Prep& P) {
+        float* as = smem + buf * (BM * KT);
+        float* bs = smem + 2 * BM * KT + buf * (BN * KT);
+        const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.pA, p.probe & 1 ? 0 : (int)OOB);   // probe: timing-only build knob
+        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.pB, p.probe & 2 ? 0 : (int)OOB);
+#pragma unroll
+        for (int j = 0; j < AIT; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(as + (j * 4 + wave) * 256), 16, (int)P.vA[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BIT; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(bs + (j * 4 + wave) * 256), 16, (int)P.vB[j], 0, 0, 0);
     };
 
     f32x16 acc[MT][NT];
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     // software pipeline over the KT/8 sub-steps: the fragments of sub-step s+1 are requested BEFORE the MFMAs of
     // sub-step s, and sched_group_barrier spreads those LDS reads between the MFMAs so no wave sits on an lgkmcnt wait
     // at a sub-step boundary
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int kt_prep, Prep& P) {
         const float* as = smem + buf * (BM * KT);
         const float* bs = smem + 2 * BM * KT + buf * (BN * KT);
         constexpr int S = KT / 8;
@@ -649,6 +663,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
 #pragma unroll
         for (int s = 0; s < S; s += 2) {
             if (s + 1 < S) load_frags(as, bs, s + 1, fa1, fb1);
+            if (s == 0) prep_tiles(kt_prep, P);   // next-but-one tile's address arithmetic: issues between this wave's MFMAs
+                                                  // (unconditional: pure arithmetic, and a branch would fence it off from them)
             mfma_group(fa0, fb0);
             if (VD_SCHED_INTERLEAVE && AK != VD_COL && BK == VD_ROW) {
 #pragma unroll
@@ -672,23 +688,26 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     };
 
     if (kt_begin < kt_end) {
-        dma_tiles(kt_begin, 0);
+        Prep P;
+        prep_tiles(kt_begin, P);
+        issue_tiles(0, P);
+        prep_tiles(kt_begin + 1, P);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int buf = 0;
         if (p.probe & 4) {           // timing probe only (wrong results): no barrier in the main loop
             for (int kt = kt_begin; kt < kt_end; ++kt) {
-                if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
-                compute(buf);
+                if (kt + 1 < kt_end) issue_tiles(buf ^ 1, P);
+                compute(buf, kt + 2, P);
                 buf ^= 1;
             }
         } else if (p.probe & 32) {      // timing probe: core-clock cycles this wave spends issuing DMA / computing / waiting
             unsigned long long t_dma = 0, t_cmp = 0, t_wait = 0;
             for (int kt = kt_begin; kt < kt_end; ++kt) {
                 const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-                if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
+                if (kt + 1 < kt_end) issue_tiles(buf ^ 1, P);
                 const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-                compute(buf);
+                compute(buf, kt + 2, P);
                 const unsigned long long c2 = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -703,8 +722,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             }
         } else
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) dma_tiles(kt + 1, buf ^ 1);
-            compute(buf);
+            if (kt + 1 < kt_end) issue_tiles(buf ^ 1, P);
+            compute(buf, kt + 2, P);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             buf ^= 1;
