@@ -501,6 +501,12 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
     // prep(t+2) is called from INSIDE compute(t), so its ~55 instructions issue in the shadow of this wave's own MFMAs: a
     // wave that spends 40 % of every tile in a serial SALU chain in front of its MFMAs (loop-phase probe, VD_GEMM_PROBE=32)
     // leaves the matrix pipe idle whenever its three neighbours do the same.
+    // where the DMA of tile t+1 is issued: right after the barrier (forward kinds: +1.5 % there, the loads get the whole tile
+    // to land) or after the fragment reads inside the MFMA section (weight-gradient kinds: +1 %)
+#ifndef VD_ISSUE_IN
+#define VD_ISSUE_IN 2        /* 0 = after the barrier, 1 = inside the MFMA section, 2 = per kind (A/B builds: tests/perf_ab.py) */
+#endif
+    constexpr bool ISSUE_IN = VD_ISSUE_IN == 2 ? (AK == VD_COL) : (VD_ISSUE_IN == 1);
     struct Prep { const float* pA; const float* pB; unsigned vA[AIT], vB[BIT]; };   // (bases, not descriptors: the resource type cannot be a field)
     auto prep_tiles = [&](int kt, Prep& P) {
         // ------------------------------------------------ A
@@ -663,8 +669,14 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
 #pragma unroll
         for (int s = 0; s < S; s += 2) {
             if (s + 1 < S) load_frags(as, bs, s + 1, fa1, fb1);
-            if (s == 0) prep_tiles(kt_prep, P);   // next-but-one tile's address arithmetic: issues between this wave's MFMAs
-                                                  // (unconditional: pure arithmetic, and a branch would fence it off from them)
+            if (s == 0) {
+                // next tile's DMA and the next-but-one tile's address arithmetic go out between this wave's MFMAs.  Both are
+                // unconditional (a branch would fence them off from the MFMAs): past the K range every offset is out of
+                // range (the DMA writes zeros into the idle buffer), a split-K slab reads one tile of its neighbour; the
+                // vmcnt(0) + barrier closing this iteration covers the extra DMA before the buffers can be reused or freed
+                if (ISSUE_IN) issue_tiles(buf ^ 1, P);
+                prep_tiles(kt_prep, P);
+            }
             mfma_group(fa0, fb0);
             if (VD_SCHED_INTERLEAVE && AK != VD_COL && BK == VD_ROW) {
 #pragma unroll
@@ -697,7 +709,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
         int buf = 0;
         if (p.probe & 4) {           // timing probe only (wrong results): no barrier in the main loop
             for (int kt = kt_begin; kt < kt_end; ++kt) {
-                if (kt + 1 < kt_end) issue_tiles(buf ^ 1, P);
+                if (!ISSUE_IN) issue_tiles(buf ^ 1, P);
                 compute(buf, kt + 2, P);
                 buf ^= 1;
             }
@@ -705,7 +717,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             unsigned long long t_dma = 0, t_cmp = 0, t_wait = 0;
             for (int kt = kt_begin; kt < kt_end; ++kt) {
                 const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-                if (kt + 1 < kt_end) issue_tiles(buf ^ 1, P);
+                if (!ISSUE_IN) issue_tiles(buf ^ 1, P);
                 const unsigned long long c1 = __builtin_amdgcn_s_memtime();
                 compute(buf, kt + 2, P);
                 const unsigned long long c2 = __builtin_amdgcn_s_memtime();
@@ -722,7 +734,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const
             }
         } else
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) issue_tiles(buf ^ 1, P);
+            if (!ISSUE_IN) issue_tiles(buf ^ 1, P);
             compute(buf, kt + 2, P);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
