@@ -378,7 +378,10 @@ __device__ __forceinline__ int row_swz_t(int row, int chunk) { return row * KT +
 // instructions per wave instead of 64 dword ones.  Used by every launch that does not ask for output statistics (their
 // per-column sums need a column per lane) when N, ldc, ldr are multiples of 4.
 template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR>
-__global__ __launch_bounds__(256, (KT == 16 ? 4 : 2)) void gemm_dma_kernel(const GemmArgs p) {
+#ifndef VD_KT16_BLOCKS
+#define VD_KT16_BLOCKS 4
+#endif
+__global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * KT];
     constexpr int MT = BM / 64, NT = BN / 64;
     constexpr int AIT = BM * KT / 1024, BIT = BN * KT / 1024;   // DMA pieces (1 KiB) per wave for A / B
@@ -1029,8 +1032,11 @@ inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk, b
 }
 
 // conv weight gradients with at least this many pixels (K of the GEMM) run the KT = 16 kernel, 4 workgroups per CU
-// (measured: +2-3 % at 128 Ki pixels, -0..20 % at 32 Ki and below)
-constexpr long long WGRAD_WIDE_PIXELS = 65536;
+// (same-box A/B, tests/perf_ab.py: +2-3 % at 128 Ki pixels, +2 % at 32 Ki, -20 % at 8 Ki)
+#ifndef VD_WGRAD_WIDE
+#define VD_WGRAD_WIDE 32768
+#endif
+constexpr long long WGRAD_WIDE_PIXELS = VD_WGRAD_WIDE;
 
 // transposed-accumulator epilogue (dwordx4 stores): whenever the launch does not want output statistics and every row is
 // 16-byte addressable
