@@ -104,6 +104,12 @@ int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t ldd
                      int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w, int32_t accumulate,
                      float* ws, size_t ws_bytes, void* stream);
+/* the same in two calls, for per-kernel timing (bench.py's live roofline figure): phase 1 = the split-K MFMA kernel into ws,
+ * phase 2 = slab reduction + OIHW transposition into dw_oihw/dbias.  Same stream, same thread, phase 1 first. */
+int vd_conv3x3_wgrad_phase(const float* xin, int64_t ldx, const float* dy, int64_t lddy,
+                           int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                           float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w, int32_t accumulate,
+                           float* ws, size_t ws_bytes, int32_t phase, void* stream);
 
 /* OIHW (Cout_w, Cin_w, 3, 3) -> wf[Cout_w][9][Cin_p]  (forward)  and/or  wd[Cin_w][9][Cout_p] with the taps
  * mirrored (dgrad).  Either output may be NULL.  Padding channels are zero-filled. */

@@ -1221,44 +1221,59 @@ extern "C" size_t vd_conv3x3_wgrad_ws_bytes(int32_t nimg, int32_t H, int32_t W, 
     return (size_t)S * ((size_t)Cout * 9 * Cin + Cout) * sizeof(float);
 }
 
-extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
-                                int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w,
-                                int32_t Cout_w, int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+// phases: 1 = split-K slabs (the MFMA kernel), 2 = slab reduction + OIHW transposition, 3 = both
+static int conv3x3_wgrad_impl(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                              int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                              int32_t accumulate, float* ws, size_t ws_bytes, hipStream_t st, int phases) {
     VD_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "vd_conv3x3_wgrad: Cin/Cout must be multiples of 4 (%d,%d)", Cin, Cout);
     VD_REQUIRE(Cin_w <= Cin && Cout_w <= Cout, "vd_conv3x3_wgrad: real dims exceed padded dims");
     int t, S;
     wgrad_plan(nimg, H, W, Cin, Cout, &t, &S);
     static const int codes[4] = {128, 12864, 64128, 64};
     VD_REQUIRE(ws && ws_bytes >= (size_t)S * ((size_t)Cout * 9 * Cin + Cout) * 4, "vd_conv3x3_wgrad: workspace too small");
-    vd_gemm_desc d = {};
-    d.A = dy; d.B = xin; d.C = ws;
-    d.M = Cout; d.N = 9 * Cin; d.K = nimg * H * W;
-    d.a_kind = VD_COL; d.b_kind = VD_IM2COL;
-    d.lda = lddy; d.ldb = ldx; d.ldc = 9LL * Cin;
-    d.batch = 1; d.nh = 1; d.alpha = 1.f;
-    d.H = H; d.W = W; d.Cin = Cin;
-    d.splitk = S; d.ws = ws; d.ws_bytes = (int64_t)ws_bytes; d.tile = codes[t];
     const long long slab = (long long)Cout * 9 * Cin;
-    int used = S;
-    float* cpart = nullptr;
-    if (S > 1) {
-        d.colsum = dbias;                      // run_gemm redirects it to the per-slab partial area behind the slabs
-        int rc = run_gemm(d, st);
-        if (rc) return rc;
-        used = g_last_slabs;
-        cpart = ws + used * slab;
-    } else {
-        d.splitk = 1;
-        cpart = ws + slab;
-        d.colsum = dbias ? cpart : nullptr; d.colsum_accumulate = 0;
+    if (phases & 1) {
+        vd_gemm_desc d = {};
+        d.A = dy; d.B = xin; d.C = ws;
+        d.M = Cout; d.N = 9 * Cin; d.K = nimg * H * W;
+        d.a_kind = VD_COL; d.b_kind = VD_IM2COL;
+        d.lda = lddy; d.ldb = ldx; d.ldc = 9LL * Cin;
+        d.batch = 1; d.nh = 1; d.alpha = 1.f;
+        d.H = H; d.W = W; d.Cin = Cin;
+        d.splitk = S; d.ws = ws; d.ws_bytes = (int64_t)ws_bytes; d.tile = codes[t];
+        if (S > 1) {
+            d.colsum = dbias;                  // run_gemm redirects it to the per-slab partial area behind the slabs
+        } else {
+            d.splitk = 1;
+            g_last_slabs = 1;
+            d.colsum = dbias ? ws + slab : nullptr; d.colsum_accumulate = 0;
+        }
         int rc = run_gemm(d, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(reduce_slabs_oihw_kernel, dim3((slab + 255) / 256), dim3(256), 0, st, ws, used, slab, Cout, Cin,
-                       Cout_w, Cin_w, dw_oihw, accumulate, cpart, dbias);
-    VD_LAUNCH_CHECK("reduce_slabs_oihw_kernel");
+    if (phases & 2) {
+        const int used = g_last_slabs;         // (thread-local: what phase 1 of this thread's last weight gradient really wrote)
+        float* cpart = ws + used * slab;
+        hipLaunchKernelGGL(reduce_slabs_oihw_kernel, dim3((slab + 255) / 256), dim3(256), 0, st, ws, used, slab, Cout, Cin,
+                           Cout_w, Cin_w, dw_oihw, accumulate, cpart, dbias);
+        VD_LAUNCH_CHECK("reduce_slabs_oihw_kernel");
+    }
     return 0;
+}
+
+extern "C" int vd_conv3x3_wgrad(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
+                                int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w,
+                                int32_t Cout_w, int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
+    return conv3x3_wgrad_impl(xin, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw_oihw, dbias, Cin_w, Cout_w, accumulate, ws, ws_bytes,
+                              (hipStream_t)stream, 3);
+}
+
+extern "C" int vd_conv3x3_wgrad_phase(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
+                                      int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w,
+                                      int32_t Cout_w, int32_t accumulate, float* ws, size_t ws_bytes, int32_t phase, void* stream) {
+    VD_REQUIRE(phase == 1 || phase == 2, "vd_conv3x3_wgrad_phase: phase must be 1 (slabs) or 2 (reduce)");
+    return conv3x3_wgrad_impl(xin, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw_oihw, dbias, Cin_w, Cout_w, accumulate, ws, ws_bytes,
+                              (hipStream_t)stream, phase);
 }
 
 extern "C" int vd_pack_conv3x3(const float* w_oihw, int32_t Cout_w, int32_t Cin_w, float* wf, int32_t Cin_p, float* wd,

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "vd_conv3x3_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_conv3x3_wgrad_phase": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _i32, _vp]),
     "vd_pack_conv3x3": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "vd_pack_conv3x3_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_gn_ws_bytes": (_sz, [_i32, _i32, _i32]),
@@ -219,9 +220,17 @@ def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
-    with _Timed("gemm_dma_kernel<{tile}, 1, 2, true, {kt}> (+reduce_slabs_oihw)", 2.0 * nimg * H * W * Cout * 9 * Cin):
-        _check(lib().vd_conv3x3_wgrad(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w,
-                                      int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad")
+    args = (ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w, int(accumulate), ws.data_ptr(),
+            ws.numel() * 4)
+    flops = 2.0 * nimg * H * W * Cout * 9 * Cin
+    if PROFILE is None:
+        _check(lib().vd_conv3x3_wgrad(*args, stream()), "vd_conv3x3_wgrad")
+        return
+    # per-kernel timing: the MFMA kernel and the slab reduction get their own event pairs (same kernels, same order)
+    with _Timed("gemm_dma_kernel<{tile}, 1, 2, true, {kt}>", flops):
+        _check(lib().vd_conv3x3_wgrad_phase(*args, 1, stream()), "vd_conv3x3_wgrad_phase")
+    with _Timed("reduce_slabs_oihw_kernel", 0.0):
+        _check(lib().vd_conv3x3_wgrad_phase(*args, 2, stream()), "vd_conv3x3_wgrad_phase")
 
 
 def im2col3x3(x, ldx, xc, nimg, H, W, Cc):
