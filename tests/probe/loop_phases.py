@@ -12,16 +12,21 @@ B, R, Cc = 128, 32, 256
 x = torch.randn(B, R, R, Cc, device=DEV); w = torch.randn(Cc, 9, Cc, device=DEV) * 0.02; y = torch.randn(B, R, R, Cc, device=DEV)
 
 def run(name, fill, nblocks):
-    dbg = torch.zeros(nblocks * 8 + 64, dtype=torch.float32, device=DEV)
+    dbg = torch.zeros(nblocks * 32 + 64, dtype=torch.float32, device=DEV)
     for _ in range(4):
         d = H.GemmDesc(); fill(d); d.stats = H.ptr(dbg); d.stats_hw = 1024
         H._check(H.lib().vd_gemm(C_.byref(d), H.stream()), "vd_gemm")
     torch.cuda.synchronize()
-    t = dbg.view(torch.int64)[: nblocks * 4].view(nblocks, 4).cpu().double()
+    tw = dbg.view(torch.int64)[: nblocks * 16].view(nblocks, 4, 4).cpu().double()
+    for wv in range(4):
+        tt = tw[:, wv]
+        tt = tt[tt[:, 3] > 0]
+        print(f"   wave {wv}: vmcnt {float((tt[:,0]/tt[:,3]).mean()):.0f}  lds+mfma {float((tt[:,1]/tt[:,3]).mean()):.0f}  barrier {float((tt[:,2]/tt[:,3]).mean()):.0f}")
+    t = tw[:, 0]
     t = t[t[:, 3] > 0]
     tot = t[:, :3].sum(1)
-    print(f"{name}: blocks {len(t)}, tiles/block {t[:,3].mean():.0f}; cycles per tile: dma-issue {float((t[:,0]/t[:,3]).mean()):.0f}  "
-          f"lds+mfma {float((t[:,1]/t[:,3]).mean()):.0f}  wait {float((t[:,2]/t[:,3]).mean()):.0f}  (shares {100*float((t[:,0]/tot).mean()):.1f} / "
+    print(f"{name}: blocks {len(t)}, tiles/block {t[:,3].mean():.0f}; cycles per tile: vmcnt-barrier {float((t[:,0]/t[:,3]).mean()):.0f}  "
+          f"lds+mfma {float((t[:,1]/t[:,3]).mean()):.0f}  barrier {float((t[:,2]/t[:,3]).mean()):.0f}  (shares {100*float((t[:,0]/tot).mean()):.1f} / "
           f"{100*float((t[:,1]/tot).mean()):.1f} / {100*float((t[:,2]/tot).mean()):.1f} %)", flush=True)
 
 def conv(d):

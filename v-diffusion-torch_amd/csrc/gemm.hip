@@ -719,19 +719,19 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
         } else if (p.probe & 32) {      // timing probe: core-clock cycles this wave spends issuing DMA / computing / waiting
             unsigned long long t_dma = 0, t_cmp = 0, t_wait = 0;
             for (int kt = kt_begin; kt < kt_end; ++kt) {
-                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
                 if (!ISSUE_IN) issue_tiles(buf ^ 1, P);
                 const unsigned long long c1 = __builtin_amdgcn_s_memtime();
                 compute(buf, kt + 2, P);
                 const unsigned long long c2 = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long c2b = __builtin_amdgcn_s_memtime();
                 __syncthreads();
                 const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-                t_dma += c1 - c0; t_cmp += c2 - c1; t_wait += c3 - c2;
+                t_dma += c2b - c2; t_cmp += c2 - c1; t_wait += c3 - c2b;      // {own DMA not landed yet, LDS reads + MFMA, barrier}
                 buf ^= 1;
             }
-            if (lane == 0 && wave == 0) {
-                const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            if (lane == 0) {
+                const unsigned lin = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
                 unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats) + 4ULL * lin;        // (probe: through `stats`)
                 o[0] = t_dma; o[1] = t_cmp; o[2] = t_wait; o[3] = (unsigned long long)(kt_end - kt_begin);
             }
