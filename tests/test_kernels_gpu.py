@@ -260,6 +260,24 @@ def test_thin_input_conv_fwd_wgrad(H, case):
     close(db, leaves[1].grad, l32[1].grad, name="thin-in db")
 
 
+def test_conv3x3_wgrad_phases_equal_the_single_call(H):
+    """vd_conv3x3_wgrad_phase(1) + (2) (what bench.py times separately) == vd_conv3x3_wgrad, bit for bit"""
+    nimg, Hh, Ww, Cin, Cout = 4, 16, 16, 64, 32
+    x, dy = nhwc(rnd(nimg, Cin, Hh, Ww, seed=1)), nhwc(rnd(nimg, Cout, Hh, Ww, seed=2))
+    dw1, db1 = torch.zeros(Cout, Cin, 3, 3, device=DEV), torch.zeros(Cout, device=DEV)
+    dw2, db2 = torch.ones(Cout, Cin, 3, 3, device=DEV), torch.ones(Cout, device=DEV)
+    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw1, Cin, Cout, dbias=db1)
+    H.PROFILE = []
+    try:
+        H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=db2)
+        names = [r[0] for r in H.PROFILE]
+    finally:
+        H.PROFILE = None
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    assert len(names) == 2 and names[0].startswith("gemm_dma_kernel<") and names[1] == "reduce_slabs_oihw_kernel"
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm family
 def ref_gn_block(x, gamma, beta, film, act, resample, mask=None):
     B, Cc = x.shape[:2]
