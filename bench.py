@@ -66,9 +66,10 @@ def usable_cpus(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(batch=8):
+def cpu_baseline(batch=16, budget_s=18.0):
     """The CPU oracle (oracle/, proved equal to the reference by the golden fixtures) doing the same train step on the
-    host cores: bounded sample, reported beside the GPU number, never the thing measured."""
+    host cores: bounded sample (batch 16; one warm-up step, then timed steps until ~budget_s of CPU
+    work), reported beside the GPU number, never the thing measured."""
     from oracle import unet_ref, diffusion_ref as dref
     from oracle.unet_ref import param_shapes
     ncpu = usable_cpus()
@@ -82,10 +83,8 @@ def cpu_baseline(batch=8):
     y = torch.randint(1, 11, (batch,), generator=g).float()
     den = lambda a, b, c: unet_ref.unet_forward(sd, CIFAR, a, b, c, train=True)
     sched = dref.make_schedule("cosine")
-    times = []
-    for it in range(2):                   # first pass warms the allocator / thread pool
-        if times and times[0] > 25.0:     # bounded sample: do not spend another > 25 s
-            break
+    times, t_start = [], time.perf_counter()
+    while True:                           # first pass warms the allocator / thread pool and is not counted
         t = torch.rand((batch,), dtype=torch.float64, generator=g)
         noise = torch.randn(x0.shape, generator=g)
         t0 = time.perf_counter()
@@ -94,13 +93,148 @@ def cpu_baseline(batch=8):
         times.append(time.perf_counter() - t0)
         for v in sd.values():
             v.grad = None
+        spent = time.perf_counter() - t_start
+        if len(times) >= 2 and (spent + times[-1] > budget_s or len(times) >= 9):
+            break
+        if len(times) == 1 and times[0] > budget_s:      # very slow host: the cold step is all the budget allows
+            break
+    timed = sorted(times[1:] or times)
+    med = timed[len(timed) // 2]
     try:
         model_name = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model_name = "unknown"
-    return {"value": round(batch / times[-1], 3), "unit": "images/s", "cores": ncpu, "kind": "port",
-            "sample": f"CIFAR-10 cond UNet train step (q_sample+fwd+v-loss+bwd, no optimizer), batch {batch}, {'1 timed step after 1 warm-up' if len(times) > 1 else 'single cold step (bounded)'}, "
+    return {"value": round(batch / med, 3), "unit": "images/s", "cores": ncpu, "kind": "port",
+            "sample": f"CIFAR-10 cond UNet train step (q_sample+fwd+v-loss+bwd, no optimizer), batch {batch}, "
+                      f"median of {len(timed)} timed step(s) after {'1 warm-up' if len(times) > 1 else 'no warm-up (bounded)'}, "
                       f"torch CPU fp32 on {ncpu} threads, {model_name}"}
+
+
+WORKLOADS = {
+    "cifar10": dict(cfg=CIFAR, res=32, fwd_gflop=FWD_GFLOP_PER_IMG,
+                    name="CIFAR-10 32x32 class-cond v-pred UNet (cifar10_cond.json, 60.8M params)"),
+    "celeba": dict(cfg=CELEBA, res=64, fwd_gflop=CELEBA_FWD_GFLOP_PER_IMG,
+                   name="CelebA 64x64 multitag v-pred UNet (celeba.json+defaults.json, 266.8M params)"),
+}
+PEAK_HBM_TBS = 8.0                     # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured for a streaming copy)
+
+
+def traffic_table():
+    """HBM bytes per launch from the committed PMC passes (profiles/parse_rocprof.py): newest round first"""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            return name, json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+        except Exception:
+            continue
+    return None, {}
+
+
+def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_steps, extras=True):
+    """build the workload's model + trainer, time `steps` train steps, then the live per-kernel roofline of two more"""
+    import v_diffusion
+    from v_diffusion import _hip
+    from v_diffusion.trainer import HotPathTrainer
+    W = WORKLOADS[wl]
+    celeba = wl == "celeba"
+    model = build_model(device, cfg=W["cfg"])
+    model.train()
+    diffusion = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), sample_steps, "v",
+                                              "fixed_medium", "snr_trunc", "mse", intp_frac=0.3, w_guide=1.0, p_uncond=0.1)
+    trainer = HotPathTrainer(model, diffusion, lr=2e-4, weight_decay=0.001, warmup=1000, grad_norm=1.0, ema_decay=0.9999,
+                             use_ema=True, rank=rank, world_size=world)
+    if os.environ.get("VD_BENCH_FORCE_REDUCER") and world == 1:
+        # multi-GPU code path on one GPU (tests/test_multigpu_path_gpu.py): a 1-rank RCCL group, bucketed all-reduce of the real
+        # gradient buffer switched on, so the bucket / launch overhead the N > 1 runs add is measurable without an 8-GPU node
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+        trainer.reducer.active = True
+    RES = W["res"]
+    g = torch.Generator(device).manual_seed(4321 + rank)
+    x = torch.rand((B, 3, RES, RES), device=device, generator=g) * 2 - 1                  # Normalize(0.5, 0.5) range
+    if celeba:
+        labels = (torch.rand((B, 40), device=device, generator=g) < 0.2).float()           # CelebA attribute tags
+    else:
+        labels = torch.randint(1, 11, (B,), device=device, generator=g).float()            # target_transform y+1
+
+    def one_step():
+        return trainer.step(x, labels.clone())          # y is mutated by the label drop: hand over a fresh copy
+
+    for _ in range(warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / steps * 1e3
+    res = dict(model=model, diffusion=diffusion, labels=labels, ms_per_step=ms_per_step, value=world * B * steps / dt,
+               final_loss=float(loss.item()), name=W["name"], res=RES, fwd_gflop=W["fwd_gflop"])
+
+    # ---- SURVEY 5 metric variants (rank-local, a few steps each): the reference loop's per-step host sync, and fwd+bwd alone
+    if extras:
+        n = max(3, min(steps, 5))
+        barrier(); t0 = time.perf_counter()
+        for _ in range(n):
+            float(one_step().item())                    # train_utils.py:169 reads loss.item() every step
+        barrier()
+        res["ms_per_step_with_loss_item"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+        tt, nn_ = trainer.draw(x)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(n):
+            diffusion.train_loss(model, x_0=x, t=tt.clone(), y=labels.clone(), noise=nn_).mean().backward()
+        barrier()
+        res["ms_fwd_bwd_only"] = round((time.perf_counter() - t0) / n * 1e3, 3)
+
+    # ---- live roofline: HIP events around every matmul-shaped and GroupNorm launch of two extra steps
+    if rank == 0:
+        _hip.PROFILE = []
+    for _ in range(2):                  # every rank takes part (the steps contain collectives); only rank 0 records
+        one_step()
+    barrier()
+    roofline = None
+    if rank == 0:
+        rec, _hip.PROFILE = _hip.PROFILE, None
+        agg, hbm = {}, {}
+        for name, work, e0, e1 in rec:
+            tgt = hbm if name.startswith("hbm:") else agg
+            a = tgt.setdefault(name, [0.0, 0.0, 0])
+            a[0] += work; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        total_t = sum(v[1] for v in agg.values())
+        dom = max(agg, key=lambda k: agg[k][1])
+        fl, tt_, n = agg[dom]
+        tname, tj = traffic_table()
+        key = dom.split(" (+")[0]
+        traffic = tj[key]["hbm_bytes_per_launch"] if key in tj else None
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / tt_ / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(fl / tt_ / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": f"HBM+fabric bytes per launch, PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/{tname}",
+                    "launches_per_step": n // 2, "avg_launch_ms": round(tt_ / n * 1e3, 4),
+                    "flops_per_launch": round(fl / n / 1e9, 3), "flops_unit": "GFLOP (2*M*N*K of the implicit GEMM)",
+                    "share_of_matmul_time": round(tt_ / total_t, 3),
+                    "all_matmul_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / 2 * 1e3, 2),
+                                               "launches_per_step": v[2] // 2} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])},
+                    "step_matmul_tflops": round(3 * W["fwd_gflop"] * B / (ms_per_step * 1e-3) / 1e3, 2)}
+        if hbm:     # the dominant HBM-bound kernel class: algorithmic bytes (operands read + written once) / live time / 8 TB/s
+            hd = max(hbm, key=lambda k: hbm[k][1])
+            by, th, nh = hbm[hd]
+            hk = hd[4:]
+            roofline["hbm"] = {"bound": "hbm", "kernel": hk, "achieved": round(by / th / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3,
+                               "unit": "GB/s", "frac": round(by / th / 1e12 / PEAK_HBM_TBS, 4),
+                               "traffic": tj[hk]["hbm_bytes_per_launch"] if hk in tj else None,
+                               "launches_per_step": nh // 2, "avg_launch_ms": round(th / nh * 1e3, 4),
+                               "bytes_per_launch": round(by / nh), "ms_per_step": round(th / 2 * 1e3, 3),
+                               "all_hbm_kernels": {k[4:]: {"gbs": round(v[0] / v[1] / 1e9, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3),
+                                                           "launches_per_step": v[2] // 2} for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}}
+    res["roofline"] = roofline
+    res["trainer"] = trainer
+    return res
 
 
 def main():
@@ -111,14 +245,12 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config: 128)")
     ap.add_argument("--no-sample", action="store_true", help="skip the DDIM-50 CFG sampling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the CelebA (BASELINE configs[3]) secondary block")
     ap.add_argument("--sample-steps", type=int, default=50)
     ap.add_argument("--config", choices=["cifar10", "celeba"], default="cifar10",
-                    help="cifar10 = the headline workload (BASELINE configs[1]); celeba = configs[3], secondary")
+                    help="cifar10 = the headline workload (BASELINE configs[1]); celeba = configs[3] as the primary line")
     args = ap.parse_args()
-    celeba = args.config == "celeba"
-    global FWD_GFLOP_PER_IMG
-    if celeba:
-        FWD_GFLOP_PER_IMG = CELEBA_FWD_GFLOP_PER_IMG
+    wl = args.config
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -134,83 +266,19 @@ def main():
         backend = os.environ.get("VD_BENCH_BACKEND", "nccl")                                  # "nccl" == RCCL on ROCm
         dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
 
-    import v_diffusion
     from v_diffusion import _hip
-    from v_diffusion.trainer import HotPathTrainer
     _hip.lib()
-
-    model = build_model(device, cfg=CELEBA if celeba else CIFAR)
-    model.train()
-    diffusion = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), args.sample_steps, "v",
-                                              "fixed_medium", "snr_trunc", "mse", intp_frac=0.3, w_guide=1.0, p_uncond=0.1)
-    trainer = HotPathTrainer(model, diffusion, lr=2e-4, weight_decay=0.001, warmup=1000, grad_norm=1.0, ema_decay=0.9999,
-                             use_ema=True, rank=rank, world_size=world)
-    B = args.batch
-    RES = 64 if celeba else 32
-    g = torch.Generator(device).manual_seed(4321 + rank)
-    x = torch.rand((B, 3, RES, RES), device=device, generator=g) * 2 - 1                  # Normalize(0.5, 0.5) range
-    if celeba:
-        labels = (torch.rand((B, 40), device=device, generator=g) < 0.2).float()           # CelebA attribute tags
-    else:
-        labels = torch.randint(1, 11, (B,), device=device, generator=g).float()            # target_transform y+1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
-        return trainer.step(x, labels.clone())          # y is mutated by the label drop: hand over a fresh copy
-
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
-    final_loss = float(loss.item())
-
-    # ---- live roofline of the dominant kernel: HIP events around every matmul-shaped launch of two extra steps
-    roofline = None
-    if rank == 0:
-        _hip.PROFILE = []
-    for _ in range(2):                  # every rank takes part (the steps contain collectives); only rank 0 records
-        one_step()
-    barrier()
-    if rank == 0:
-        rec, _hip.PROFILE = _hip.PROFILE, None
-        agg = {}
-        for name, flops, e0, e1 in rec:
-            a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
-        total_t = sum(v[1] for v in agg.values())
-        dom = max(agg, key=lambda k: agg[k][1])
-        fl, tt, n = agg[dom]
-        traffic = None
-        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/parse_rocprof.py)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
-            key = dom.split(" (+")[0]
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / tt / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": "HBM+fabric bytes per launch, PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r01_traffic.json",
-                    "launches_per_step": n // 2, "avg_launch_ms": round(tt / n * 1e3, 4),
-                    "flops_per_launch": round(fl / n / 1e9, 3), "flops_unit": "GFLOP (2*M*N*K of the implicit GEMM)",
-                    "share_of_matmul_time": round(tt / total_t, 3),
-                    "all_matmul_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / 2 * 1e3, 2),
-                                               "launches_per_step": v[2] // 2} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])},
-                    "step_matmul_tflops": round(3 * FWD_GFLOP_PER_IMG * B / (ms_per_step * 1e-3) / 1e3, 2)}
+    B = args.batch
+    r = run_training(wl, B, args.steps, args.warmup, device, rank, world, barrier, args.sample_steps)
+    model, diffusion, labels, RES = r["model"], r["diffusion"], r["labels"], r["res"]
+    fwd_gflop = r["fwd_gflop"]
+    hbm_peak = torch.cuda.max_memory_allocated(device)
 
     # ---- sampling: DDIM-50 + classifier-free guidance (w=1): 2B UNet rows per step
     sampling = None
@@ -231,29 +299,57 @@ def main():
         T = args.sample_steps
         sampling = {"metric": f"ddim{T}_cfg_samples_per_sec", "value": round(world * SB / ds, 2), "unit": "images/s",
                     "seconds_per_batch": round(ds, 3), "batch_per_gpu": SB, "unet_rows_per_step": 2 * SB, "w_guide": 1.0,
-                    "matmul_tflops": round(T * 2 * FWD_GFLOP_PER_IMG * SB / ds / 1e3, 2),
-                    "frac_of_fp32_mfma_peak": round(T * 2 * FWD_GFLOP_PER_IMG * SB / ds / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "matmul_tflops": round(T * 2 * fwd_gflop * SB / ds / 1e3, 2),
+                    "frac_of_fp32_mfma_peak": round(T * 2 * fwd_gflop * SB / ds / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "finite": bool(torch.isfinite(out).all())}
         model.train()
+
+    # ---- secondary workload (BASELINE configs[3]): CelebA 64x64, per-GPU batch 128, train steps only -- short, so the default
+    # run stays within minutes; its sampling figure is `--config celeba`
+    secondary = None
+    if wl == "cifar10" and not args.no_secondary and B == 128:
+        del model, diffusion
+        r.pop("trainer"); r.pop("model"); r.pop("diffusion")
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(device)
+        r2 = run_training("celeba", 128, 5, 2, device, rank, world, barrier, args.sample_steps, extras=False)
+        rf = r2["roofline"]
+        secondary = {"metric": "train_images_per_sec", "value": round(r2["value"], 2), "unit": "images/s", "steps": 5, "warmup": 2,
+                     "ms_per_step": round(r2["ms_per_step"], 3),
+                     "config": {"workload": r2["name"] + " full train step (BASELINE configs[3])", "global_batch": world * 128,
+                                "per_gpu_batch": 128, "resolution": 64, "final_loss": round(r2["final_loss"], 5)},
+                     "frac_of_fp32_mfma_peak_whole_step": round(3 * r2["fwd_gflop"] * 128 / (r2["ms_per_step"] * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                     "roofline": None if rf is None else {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                                              "launches_per_step", "avg_launch_ms", "flops_per_launch",
+                                                                              "share_of_matmul_time", "step_matmul_tflops")}}
+        if rf is not None:
+            top = sorted(rf["all_matmul_kernels"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:8]
+            secondary["roofline"]["top_matmul_kernels"] = dict(top)
+            if "hbm" in rf:
+                secondary["roofline"]["hbm"] = {k: rf["hbm"][k] for k in ("kernel", "achieved", "unit", "frac", "ms_per_step")}
+        del r2
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
     if rank == 0:
-        line = {"metric": "train_images_per_sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        line = {"metric": "train_images_per_sec", "value": round(r["value"], 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-                "config": {"workload": ("CelebA 64x64 multitag v-pred UNet (celeba.json+defaults.json, 266.8M params)" if celeba else
-                                        "CIFAR-10 32x32 class-cond v-pred UNet (cifar10_cond.json, 60.8M params)") + " full train step: "
-                                       "q_sample+fwd+snr_trunc v-loss+bwd+grad all-reduce+clip+AdamW+EMA; second figure: DDIM-50 CFG w=1 sampling",
+                "config": {"workload": r["name"] + " full train step: q_sample+fwd+snr_trunc v-loss+bwd+grad all-reduce+clip+AdamW+EMA; "
+                                       "second figure: DDIM-50 CFG w=1 sampling",
                            "global_batch": world * B, "per_gpu_batch": B, "resolution": RES, "parallelism": f"dp{world}",
-                           "final_loss": round(final_loss, 5)},
-                "frac_of_fp32_mfma_peak_whole_step": round(3 * FWD_GFLOP_PER_IMG * B / (ms_per_step * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
-                "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
-                "roofline": roofline, "cpu_baseline": cpu, "sampling": sampling}
+                           "final_loss": round(r["final_loss"], 5)},
+                "frac_of_fp32_mfma_peak_whole_step": round(3 * fwd_gflop * B / (r["ms_per_step"] * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "ms_per_step_with_loss_item": r.get("ms_per_step_with_loss_item"), "ms_fwd_bwd_only": r.get("ms_fwd_bwd_only"),
+                "hbm_peak_gib": round(hbm_peak / 2 ** 30, 2),
+                "roofline": r["roofline"], "cpu_baseline": cpu, "sampling": sampling, "secondary": secondary}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -674,7 +674,7 @@ def test_kernel_variants_in_subprocess(H, knobs):
     env = dict(os.environ, **knobs)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_kernels_gpu.py"), "-q", "-x", "--no-header",
-                        "-p", "no:cacheprovider", "-k", "gemm_kinds or conv3x3_forward or conv3x3_dgrad or conv3x3_wgrad or batched_heads or test_gemm_splitk or colsum"],
+                        "-p", "no:cacheprovider", "-k", "gemm_kinds or conv3x3_forward or conv3x3_dgrad or conv3x3_wgrad or batched_heads or test_gemm_splitk or colsum or gn_stats_from_producer_epilogues"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

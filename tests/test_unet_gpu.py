@@ -612,3 +612,104 @@ def test_sampler_properties_full_size(vd):
     with torch.no_grad():
         e = model(torch.zeros((0, 3, 32, 32), device=DEV), torch.zeros((0,), dtype=torch.float64, device=DEV), torch.zeros((0,), device=DEV))
     assert e.shape == (0, 3, 32, 32)
+
+
+def test_per_sample_steps_and_rescaled_time_vs_golden(vd, golden_dir):
+    """(a) p_sample_step with a NON-UNIFORM (B,) step tensor (reference :360-392), (b) samplers and train_loss under a
+    rescaling schedule: the network is called with the rewritten t (reference :105-109,363-374; round-1 advisor finding).
+    Fixtures: oracle/make_goldens_r2.py."""
+    from oracle.cases import TINY
+    from oracle import detrand
+    g = _gold(golden_dir, "r2_steps.npz")
+    case = TINY["tinyA"]
+    model, _ = _build(vd, case["cfg"], train=False)
+    B, R, T = 4, case["R"], 8
+    shape = (B, 3, R, R)
+    xs = detrand.normal("ps_x", shape, 31)
+    y = torch.tensor([1.0, 7.0, 10.0, 3.0])
+    nz = detrand.normal("ps_noise", shape, 32)
+
+    def fake_normal_(self, *a, **k):
+        return self.copy_(nz.to(self.device))
+    for tag, kw in (("ddim_cfg", dict(use_ddim=True, w_guide=1.0, vt="fixed_large", frac=None)),
+                    ("ddpm_medium_cfg", dict(use_ddim=False, w_guide=0.5, vt="fixed_medium", frac=0.3)),
+                    ("ddpm_large_nocfg", dict(use_ddim=False, w_guide=0.0, vt="fixed_large", frac=None))):
+        gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine", -20.0, 20.0), T, "v", kw["vt"], "snr_trunc", "mse",
+                                  intp_frac=kw["frac"], w_guide=kw["w_guide"], p_uncond=0.0)
+        step = torch.tensor([0.0, 3.0, 7.0, 5.0], dtype=torch.float64, device=DEV)
+        with torch.no_grad(), mock.patch.object(torch.Tensor, "normal_", fake_normal_):
+            sample, pred = gd.p_sample_step(model, xs.to(DEV), step, y.to(DEV), return_pred=True, use_ddim=kw["use_ddim"])
+        for name, got in (("sample", sample), ("pred", pred)):
+            err = np.abs(got.cpu().numpy() - g[f"step_{tag}_{name}"]).max()
+            assert err <= 1e-4 * max(1.0, float(np.abs(g[f"step_{tag}_{name}"]).max())), f"{tag}/{name}: {err:.3e}"
+        # a uniform step through the per-sample composition == the fused step kernel
+        for ti in (0, 5):
+            st = torch.full((B,), float(ti), dtype=torch.float64, device=DEV)
+            with torch.no_grad(), mock.patch.object(torch.Tensor, "normal_", fake_normal_):
+                a = gd.p_sample_step(model, xs.to(DEV), st, y.to(DEV), use_ddim=kw["use_ddim"])
+                b = gd._p_sample_step_per_sample(model, xs.to(DEV), st, y.to(DEV), None, True, False, kw["use_ddim"])
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item()), (tag, ti)
+    noises = [detrand.normal(f"rs_step{k}", shape, 33) for k in range(T)]
+    x_T = detrand.normal("rs_xT", shape, 34)
+    for tag, rescale in (("bool", True), ("half", 0.5)):
+        gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine", -20.0, 20.0, rescale=rescale), T, "v", "fixed_large", "snr_trunc",
+                                  "mse", w_guide=1.0, p_uncond=0.0)
+        for use_graph in (False, True):
+            order = iter(reversed(range(T)))
+
+            def fake_seq_(self, *a, **k):
+                return self.copy_(noises[next(order)].to(self.device))
+            with mock.patch.object(torch.Tensor, "normal_", fake_seq_):
+                x = gd.p_sample(model, shape, noise=x_T.clone(), label=y.clone(), device=DEV, seed=None, use_ddim=True,
+                                use_graph=use_graph)
+            err = np.abs(x.numpy() - g[f"rescale_{tag}"]).max()
+            assert err <= 1e-4, f"rescale={rescale} graph={use_graph}: trajectory end differs by {err:.3e}"
+        t = detrand.uniform("rs_t", (B,), 35, dtype=torch.float64)
+        with torch.no_grad():
+            loss = gd.train_loss(model, xs.clamp(-1, 1).to(DEV), t.to(DEV), y.to(DEV), nz.to(DEV))
+        np.testing.assert_allclose(loss.cpu().numpy(), g[f"rescale_{tag}_loss"], rtol=2e-4, atol=1e-6)
+
+
+def test_class_conditional_net_without_labels_has_zero_class_gradients(vd):
+    """num_classes > 0 called with y=None (round-1 advisor finding): the reference leaves class_embed gradients None; here
+    every gradient target is written, so they must be exact zeros -- with and without the trainer's flat buffers -- and all
+    other gradients must equal the oracle's."""
+    from oracle import unet_ref
+    from oracle.cases import TINY, make_inputs
+    case = TINY["tinyA"]
+    cfg = case["cfg"]
+    model, sd = _build(vd, cfg, train=True)
+    x, t, _ = make_inputs(cfg, 3, case["R"], case["label"], seed=2)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    unet_ref.unet_forward(sdo, cfg, x, t, None).square().sum().backward()
+    for poison in (False, True):
+        model.zero_grad(set_to_none=True)
+        if poison:                                          # flat gradient views holding the previous step's values
+            views = {k: torch.full_like(p, 7.0) for k, p in model.named_parameters()}
+            model._flat_grad_views = views
+        model(x.to(DEV), t.to(DEV), None).square().sum().backward()
+        grads = views if poison else {k: p.grad for k, p in model.named_parameters()}
+        model._flat_grad_views = None
+        gmax = max(v.grad.norm().item() for k, v in sdo.items() if v.grad is not None)
+        for k, gr in grads.items():
+            if k.startswith("class_embed."):
+                assert sdo[k].grad is None or float(sdo[k].grad.abs().max()) == 0
+                assert float(gr.abs().max()) == 0.0, k
+            else:
+                assert (gr.cpu() - sdo[k].grad).norm().item() <= 1e-4 * sdo[k].grad.norm().item() + 1e-6 * gmax, k
+
+
+def test_async_uint8_sample_export(vd):
+    """p_sample_uint8_async == quantised p_sample (reference generate.py:143-150), delivered through pinned memory"""
+    from oracle.cases import TINY
+    case = TINY["tinyA"]
+    model, _ = _build(vd, case["cfg"], train=False)
+    gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine"), 4, "v", "fixed_large", "snr_trunc", "mse", w_guide=1.0)
+    shape, y = (5, 3, case["R"], case["R"]), torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0])
+    x = gd.p_sample(model, shape, label=y, seed=3, use_ddim=True)                    # device defaults to the model's
+    pend = [gd.p_sample_uint8_async(model, shape, label=y, seed=3, use_ddim=True) for _ in range(2)]
+    want = (x * 127.5 + 127.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    for p in pend:
+        got = p.numpy()
+        assert got.dtype == np.uint8 and got.shape == want.shape and p.tensor().is_pinned() and p.ready()
+        assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1      # (round-to-nearest vs truncation at .5 ties)

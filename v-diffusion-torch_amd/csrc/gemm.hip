@@ -784,39 +784,48 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const f32x4 al4 = {p.alpha, p.alpha, p.alpha, p.alpha};
         constexpr int NQ = 4 * NT;
+        // the 8 column quads of a row block are handled in two halves of 4: bias / residual / offset staging for all 8 at once
+        // (72 live registers beside the 64 accumulators) spilled to scratch under the 128-VGPR cap of the 4-workgroups-per-CU
+        // KT = 16 forms (11-60 spilled VGPRs, tests/test_host_cpu.py::test_no_kernel_spills_to_scratch)
+        constexpr int NQH = NQ > 4 ? NQ / 2 : NQ;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int rowl = wm + (A2 ? 2 * li + a : 32 * a + li);
-            f32x4 bias4[NQ], add4[NQ];
-            unsigned vocs[NQ];
 #pragma unroll
-            for (int e = 0; e < NQ; ++e) {
-                const int ncol = B2 ? wn + 16 * (e >> 1) + 8 * lh + 4 * (e & 1) : wn + 32 * (e >> 2) + 8 * (e & 3) + 4 * lh;
-                const int n = n0 + ncol;
-                const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
-                vocs[e] = nok ? (unsigned)(rowl * ldc4 + ncol * 4) : OOB;
-                const unsigned vor = nok ? (unsigned)(rowl * ldr4 + ncol * 4) : OOB;
-                bias4[e] = (!SPLITK && biasp && nok) ? *reinterpret_cast<const f32x4*>(biasp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (!SPLITK) {
-                    if (R) t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0));
-                    if (p.accumulate) t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (int)vocs[e], 0, 0));
-                }
-                add4[e] = t;
-            }
+            for (int e0 = 0; e0 < NQ; e0 += NQH) {
+                f32x4 bias4[NQH], add4[NQH];
+                unsigned vocs[NQH];
 #pragma unroll
-            for (int e = 0; e < NQ; ++e) {
-                f32x4 v;
-                if (B2) {
-                    const int r0 = 4 * (e >> 1) + 2 * (e & 1);
-                    v = f32x4{acc[a][0][r0], acc[a][NT - 1][r0], acc[a][0][r0 + 1], acc[a][NT - 1][r0 + 1]};
-                } else {
-                    const int b = e >> 2, q = e & 3;
-                    v = f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                for (int ee = 0; ee < NQH; ++ee) {
+                    const int e = e0 + ee;
+                    const int ncol = B2 ? wn + 16 * (e >> 1) + 8 * lh + 4 * (e & 1) : wn + 32 * (e >> 2) + 8 * (e & 3) + 4 * lh;
+                    const int n = n0 + ncol;
+                    const bool nok = (BK == VD_IM2COL) ? (ci0 + ncol < p.Cin) : (n < p.N);
+                    vocs[ee] = nok ? (unsigned)(rowl * ldc4 + ncol * 4) : OOB;
+                    const unsigned vor = nok ? (unsigned)(rowl * ldr4 + ncol * 4) : OOB;
+                    bias4[ee] = (!SPLITK && biasp && nok) ? *reinterpret_cast<const f32x4*>(biasp + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (!SPLITK) {
+                        if (R) t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0));
+                        if (p.accumulate) t += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (int)vocs[ee], 0, 0));
+                    }
+                    add4[ee] = t;
                 }
-                if (!SPLITK) v = (v * al4 + bias4[e]) + add4[e];
-                const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(u, crs, (int)vocs[e], 0, 0);
+#pragma unroll
+                for (int ee = 0; ee < NQH; ++ee) {
+                    const int e = e0 + ee;
+                    f32x4 v;
+                    if (B2) {
+                        const int r0 = 4 * (e >> 1) + 2 * (e & 1);
+                        v = f32x4{acc[a][0][r0], acc[a][NT - 1][r0], acc[a][0][r0 + 1], acc[a][NT - 1][r0 + 1]};
+                    } else {
+                        const int b = e >> 2, q = e & 3;
+                        v = f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                    }
+                    if (!SPLITK) v = (v * al4 + bias4[ee]) + add4[ee];
+                    const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(u, crs, (int)vocs[ee], 0, 0);
+                }
             }
         }
         stamp_end();
@@ -982,7 +991,6 @@ __global__ void pack_conv3x3_batched_kernel(const long long* items, int n) {
 }
 
 thread_local int g_last_tile = 0;
-thread_local int g_last_slabs = 1;     // slabs the last split-K launch really wrote
 
 bool use_dma(const GemmArgs& a) {
     static const bool legacy = getenv("VD_GEMM_LEGACY") != nullptr;       // A/B switch for profiling
@@ -1023,9 +1031,10 @@ int choose_tile(long long M, long long Ncols, bool wgrad, long long zcount, int 
 // and KT = 16 (32 KB LDS, ~106 VGPRs: 4 per CU): the deeper occupancy wins (+2-3 %) only when the launch has enough
 // workgroups to give every CU four of them (>= 1024); short launches keep the longer K tile.  `wide` = the caller
 // (conv weight gradient with >= 64 Ki pixels) sized its split-K slabs for 4 workgroups per CU.
-inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk, bool wide) {
+inline int ktile_for(const GemmArgs& a, int t, long long nblocks, bool splitk, bool wide, bool wgrad_unsplit = false) {
     static const char* force = getenv("VD_GEMM_KT");
     if (t != 0 || !use_dma(a)) return KT;
+    if (wgrad_unsplit) return KT;                  // (no KT = 16 build of that form, see launch<>)
     if (force) return atoi(force) == 16 ? 16 : 32;
     if (splitk) return wide ? 16 : 32;
     return nblocks >= 1024 ? 16 : 32;           // 1024 workgroups = four per CU, all resident (measured: +0.7 % on the sampler)
@@ -1053,7 +1062,9 @@ bool use_tr(const GemmArgs& a, bool wgrad) {
 
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
-    constexpr bool has16 = BM == 128 && BN == 128;       // the only tile with a KT = 16 instantiation
+    // the only tile with a KT = 16 instantiation; an unsplit conv weight gradient never takes it (ktile_for): those two
+    // instantiations carried 11 spilled VGPRs, so they are not built at all
+    constexpr bool has16 = BM == 128 && BN == 128 && !(BK == VD_IM2COL && !SPLITK);
     const bool k16 = has16 && ktile == 16;
     const bool tr = use_dma(a) && use_tr(a, BK == VD_IM2COL);
     g_last_tile = ((((tr ? 1 : 0) * 100 + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
@@ -1126,7 +1137,7 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
         VD_REQUIRE(d.stats_hw > 0 && d.stats_hw % (tbm / 2) == 0 && d.M % d.stats_hw == 0,
                    "vd_gemm: output statistics need H*W (%d) to be a multiple of half the row tile (%d)", d.stats_hw, tbm / 2);
     }
-    const int ktile = ktile_for(a, tile, nm * nn * batch, splitk > 1, wgrad && (long long)d.K >= WGRAD_WIDE_PIXELS);
+    const int ktile = ktile_for(a, tile, nm * nn * batch, splitk > 1, wgrad && (long long)d.K >= WGRAD_WIDE_PIXELS, wgrad && splitk <= 1);
     a.kt_total = conv ? 9 * ((d.Cin + ktile - 1) / ktile) : (d.K + ktile - 1) / ktile;
     a.kt_per_split = a.kt_total;
 
@@ -1134,7 +1145,6 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     if (splitk > 1) {
         a.kt_per_split = (a.kt_total + splitk - 1) / splitk;
         const int used = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;
-        g_last_slabs = used;
         a.slab_stride = (long long)d.M * d.N;
         VD_REQUIRE(d.ws && d.ws_bytes >= (int64_t)((used * a.slab_stride + (d.colsum ? (long long)used * d.M : 0)) * 4),
                    "vd_gemm: split-K workspace too small");
@@ -1232,6 +1242,17 @@ static int conv3x3_wgrad_impl(const float* xin, int64_t ldx, const float* dy, in
     static const int codes[4] = {128, 12864, 64128, 64};
     VD_REQUIRE(ws && ws_bytes >= (size_t)S * ((size_t)Cout * 9 * Cin + Cout) * 4, "vd_conv3x3_wgrad: workspace too small");
     const long long slab = (long long)Cout * 9 * Cin;
+    // slabs phase 1 writes = what run_gemm derives from (K tile, requested split): recomputed here from the arguments alone, so
+    // the two phases of vd_conv3x3_wgrad_phase share no hidden state (any thread, any interleaving with other launches)
+    int used = 1;
+    if (S > 1) {
+        GemmArgs ga = {};
+        ga.A = dy; ga.B = xin; ga.lda = lddy; ga.ldb = ldx; ga.ldc = 9LL * Cin; ga.ldr = 0;
+        const long long K = (long long)nimg * H * W;
+        const int ktile = ktile_for(ga, t, 0, true, K >= WGRAD_WIDE_PIXELS);
+        const long long kt_total = (K + ktile - 1) / ktile, per = (kt_total + S - 1) / S;
+        used = (int)((kt_total + per - 1) / per);
+    }
     if (phases & 1) {
         vd_gemm_desc d = {};
         d.A = dy; d.B = xin; d.C = ws;
@@ -1245,14 +1266,12 @@ static int conv3x3_wgrad_impl(const float* xin, int64_t ldx, const float* dy, in
             d.colsum = dbias;                  // run_gemm redirects it to the per-slab partial area behind the slabs
         } else {
             d.splitk = 1;
-            g_last_slabs = 1;
             d.colsum = dbias ? ws + slab : nullptr; d.colsum_accumulate = 0;
         }
         int rc = run_gemm(d, st);
         if (rc) return rc;
     }
     if (phases & 2) {
-        const int used = g_last_slabs;         // (thread-local: what phase 1 of this thread's last weight gradient really wrote)
         float* cpart = ws + used * slab;
         hipLaunchKernelGGL(reduce_slabs_oihw_kernel, dim3((slab + 255) / 256), dim3(256), 0, st, ws, used, slab, Cout, Cin,
                            Cout_w, Cin_w, dw_oihw, accumulate, cpart, dbias);

@@ -267,7 +267,31 @@ def gn_stats(x, ldx, nimg, HW, Cc, stats, G=32, eps=1e-6):
            "vd_gn_stats")
 
 
+class _TimedBytes:
+    """PROFILE record of an HBM-bound launch: ("hbm:<name>", algorithmic bytes = operands read + written once, events)"""
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None and exc[0] is None:
+            self.e1.record()
+            PROFILE.append(("hbm:" + self.name, float(self.nbytes), self.e0, self.e1))
+
+
 def gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G=32):
+    hw_out = H * W // 4 if resample == RS_DOWN else (H * W * 4 if resample == RS_UP else H * W)
+    with _TimedBytes("gn_apply" if gamma is not None else "resample", 4.0 * nimg * Cc * (H * W + hw_out)):
+        _gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G)
+
+
+def _gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G=32):
     _check(lib().vd_gn_apply(ptr(x), ldx, ptr(stats), ptr(gamma), ptr(beta), ptr(film), int(act), float(p_drop), int(seed),
                              resample, ptr(y), ldy, nimg, H, W, Cc, G, ptr(coef), stream()), "vd_gn_apply")
 
@@ -276,6 +300,15 @@ def gn_apply_bwd(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, r
                  accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G=32):
     nb = lib().vd_gn_ws_bytes(nimg, H * W, Cc)
     ws = workspace(nb, dy.device, "gn")
+    hw_dy = H * W // 4 if resample == RS_DOWN else (H * W * 4 if resample == RS_UP else H * W)
+    nbytes = 4.0 * nimg * Cc * (hw_dy + H * W * (1 + (gamma is not None) + (add is not None) + bool(accumulate_dx)))
+    with _TimedBytes("gn_apply_bwd" if gamma is not None else "resample_bwd", nbytes):
+        _gn_apply_bwd_call(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
+                           accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G, ws)
+
+
+def _gn_apply_bwd_call(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
+                       accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G, ws):
     _check(lib().vd_gn_apply_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(coef), ptr(gamma), ptr(beta), ptr(film), int(act),
                                  float(p_drop), int(seed), resample, ptr(add), ldadd, ptr(dx), lddx, int(accumulate_dx),
                                  ptr(dfilm), ptr(dgamma), ptr(dbeta), int(accumulate_params), nimg, H, W, Cc, G,

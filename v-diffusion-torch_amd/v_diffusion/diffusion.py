@@ -24,6 +24,86 @@ from .functions import flat_mean
 F64 = torch.float64
 
 
+
+# ------------------------------------------------------------------------------------------------ small public helpers
+def broadcast_to(arr, x, dtype=None, device=None, ndim=None):
+    """``arr`` as a tensor shaped (-1, 1, 1, ...) with x's dtype / device / rank (reference :19-27)"""
+    if x is not None:
+        dtype, device, ndim = dtype or x.dtype, device or x.device, ndim or x.ndim
+    return torch.as_tensor(arr, dtype=dtype, device=device).reshape((-1,) + (1,) * (ndim - 1))
+
+
+def repeat_along_dim(x: torch.Tensor, repeats: int, dim: int = 0):
+    """every slice along ``dim`` repeated ``repeats`` times in place: [a, b] -> [a, a, b, b] (reference :30-35)"""
+    return x.repeat_interleave(repeats, dim=dim) if repeats != 1 else x.contiguous()
+
+
+def slice_along_batch(x: torch.Tensor, span: int):
+    """the ``span`` interleaved sub-batches x[i::span] (reference :38-39)"""
+    return [x[i::span, ...] for i in range(span)]
+
+
+def _per_sample(logsnr, x):
+    """(B,) float32 log-SNR vector of a per-sample (B,1,1,1)-shaped argument, or None when it is not one value per sample"""
+    if not torch.is_tensor(logsnr) or not x.is_cuda or x.dtype != torch.float32 or x.ndim != 4:
+        return None
+    if logsnr.numel() != x.shape[0] or logsnr.device != x.device:
+        return None
+    return logsnr.reshape(-1).to(torch.float32).contiguous()
+
+
+def q_sample(x_0, logsnr_t, eps=None):
+    """x_t = alpha * x_0 + sigma * eps with alpha^2 = sigmoid(logsnr), sigma^2 = sigmoid(-logsnr) (reference :242-245).
+    One per-sample log-SNR per image on the device = the fused ``vd_q_sample`` kernel; other broadcast shapes = the
+    same expression in tensor ops."""
+    if eps is None:
+        eps = torch.randn_like(x_0)
+    l = _per_sample(logsnr_t, x_0)
+    if l is not None and eps.shape == x_0.shape and eps.dtype == torch.float32:
+        x_0, eps = x_0.contiguous(), eps.contiguous()
+        out = torch.empty_like(x_0)
+        with torch.cuda.device(x_0.device):
+            _hip.q_sample(x_0, eps, l, out, x_0.shape[0], x_0.shape[1], x_0[0, 0].numel())
+        return out
+    return x_0 * torch.sigmoid(logsnr_t).sqrt() + eps * torch.sigmoid(-logsnr_t).sqrt()
+
+
+def q_mean_var(x_0, logsnr_t):
+    """mean and log-variance of q(x_t | x_0) (reference :248-250)"""
+    return x_0 * torch.sigmoid(logsnr_t).sqrt(), F.logsigmoid(-logsnr_t)
+
+
+# conversions between the parameterisations (reference :206-239); alpha = sqrt(sigmoid(l)), sigma = sqrt(sigmoid(-l)),
+# so 1/alpha = rsqrt(sigmoid(l)), sigma/alpha = exp(-l/2), alpha/sigma = exp(l/2), 1/sigma = rsqrt(sigmoid(-l))
+def pred_x0_from_eps(x_t, eps, logsnr_t):
+    return x_t * torch.sigmoid(logsnr_t).rsqrt() - eps * torch.exp(-0.5 * logsnr_t)
+
+
+def pred_x0_from_x0eps(x_t, x0eps, logsnr_t):
+    x_0, eps = x0eps.chunk(2, dim=1)
+    return x_0 * torch.sigmoid(-logsnr_t) + pred_x0_from_eps(x_t, eps, logsnr_t) * torch.sigmoid(logsnr_t)
+
+
+def pred_eps_from_x0(x_t, x_0, logsnr_t):
+    return x_t * torch.sigmoid(-logsnr_t).rsqrt() - x_0 * torch.exp(0.5 * logsnr_t)
+
+
+def pred_v_from_x0eps(x_0, eps, logsnr_t):
+    return eps * torch.sigmoid(logsnr_t).sqrt() - x_0 * torch.sigmoid(-logsnr_t).sqrt()
+
+
+def pred_v_from_x0(x_t, x_0, logsnr_t):
+    return x_t * torch.exp(0.5 * logsnr_t) - x_0 * torch.sigmoid(-logsnr_t).rsqrt()
+
+
+def pred_x0_from_v(x_t, v, logsnr_t):
+    return x_t * torch.sigmoid(logsnr_t).sqrt() - v * torch.sigmoid(-logsnr_t).sqrt()
+
+
+def pred_eps_from_v(x_t, v, logsnr_t):
+    return x_t * torch.sigmoid(-logsnr_t).sqrt() + v * torch.sigmoid(logsnr_t).sqrt()
+
+
 # ------------------------------------------------------------------------------------------------ schedules
 def stable_log1mexp(x):
     """log(1 - e^x), x < 0 (reference :115-123)"""
@@ -200,6 +280,34 @@ class _KLLoss(torch.autograd.Function):
         return dout, None, None, None, None, None
 
 
+class PendingImages:
+    """uint8 HWC images on their way to pinned host memory (see ``GaussianDiffusion.p_sample_uint8_async``)."""
+    _side = {}
+
+    def __init__(self, u8_dev):
+        dev = u8_dev.device
+        side = PendingImages._side.get(dev)
+        if side is None:
+            side = PendingImages._side[dev] = torch.cuda.Stream(dev)
+        self.host = torch.empty(u8_dev.shape, dtype=torch.uint8, pin_memory=True)
+        self.done = torch.cuda.Event()
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.host.copy_(u8_dev, non_blocking=True)
+            self.done.record(side)
+        u8_dev.record_stream(side)
+
+    def ready(self):
+        return self.done.query()
+
+    def tensor(self):
+        self.done.synchronize()
+        return self.host
+
+    def numpy(self):
+        return self.tensor().numpy()
+
+
 class GaussianDiffusion:
     def __init__(self, logsnr_fn, sample_timesteps, model_out_type, model_var_type, reweight_type, loss_type,
                  intp_frac=None, w_guide=0.1, p_uncond=0.1, x0eps_coef=False):
@@ -267,6 +375,29 @@ class GaussianDiffusion:
         return (mean, logvar, pred) if return_pred else (mean, logvar)
 
     # ------------------------------------------------------------------------------------------ training
+    def from_model_out_to_pred(self, x_t, model_out, logsnr_t):
+        """{reweight_type: regression target counterpart} of a network output (reference :466-490): x0 for "constant",
+        eps for "snr", (x0, eps) for "snr_trunc", v for "snr_1plus".  ``train_loss`` does not call this (its fused kernel
+        evaluates the same conversions per element); kept for callers of the reference API."""
+        mot = self.model_out_type
+        if mot == "v":
+            v = model_out
+            x_0, eps = pred_x0_from_v(x_t, v, logsnr_t), pred_eps_from_v(x_t, v, logsnr_t)
+        else:
+            if mot == "x0":
+                x_0 = model_out
+                eps = pred_eps_from_x0(x_t, x_0, logsnr_t)
+            elif mot == "eps":
+                eps = model_out
+                x_0 = pred_x0_from_eps(x_t, eps, logsnr_t)
+            elif mot == "both":
+                x_0 = pred_x0_from_x0eps(x_t, model_out, logsnr_t)
+                eps = pred_eps_from_x0(x_t, x_0, logsnr_t)
+            else:
+                raise NotImplementedError(mot)
+            v = pred_v_from_x0eps(x_0, eps, logsnr_t)
+        return {"constant": x_0, "snr": eps, "snr_trunc": (x_0, eps), "snr_1plus": v}
+
     def train_loss(self, denoise_fn, x_0, t, y, noise=None):
         """Per-sample loss (B,) -- reference :492-545, mse branch.  ``y`` is mutated in place by the label drop
         (after the forward, reference quirk :527-529), which consumes one ``torch.rand(B)`` of the global CPU RNG."""
@@ -400,10 +531,11 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------------------------------ sampling
     def _step_coefs(self, step, use_ddim):
-        """The 8 floats of vd_sample_step for reverse step ``step`` (python int)."""
+        """(the 8 floats of vd_sample_step for reverse step ``step`` (python int), the time the network is called with)."""
         T = self.sample_timesteps
         st = torch.tensor([step / T, (step + 1) / T], dtype=F64)
-        l = self.logsnr_fn(st)
+        l = self.logsnr_fn(st)                                 # a rescaling schedule rewrites st in place (:105-109)
+        t_net = float(st[1])                                   # ... and the network is called with THAT t (:363-374)
         ls32, lt32 = l[0:1].float(), l[1:2].float()            # cast to the image dtype before the posterior (:365)
         if use_ddim:
             c1, c2, lv = logsnr_to_posterior_ddim(ls32, lt32, eta=0., x0eps_coef=self.x0eps_coef)
@@ -418,16 +550,17 @@ class GaussianDiffusion:
             l = lt32[0].double()
             alpha, rsig = float(torch.sigmoid(l).sqrt()), float(torch.sigmoid(-l).rsqrt())
             c1, c2 = c1 * rsig, c2 - c1 * alpha * rsig
-        return [a0, b0x, b0e, c1, c2, nscale, float(self.w_guide), 0.0]
+        return [a0, b0x, b0e, c1, c2, nscale, float(self.w_guide), 0.0], t_net
 
     def _use_cfg(self, y):
         return (self.w_guide > 0) and (y is not None)
 
-    def _reverse_step(self, denoise_fn, x_t, x_in, t_in, y_in, step, cfg, noise, use_ddim, clip, want_pred, x_next, x_dup):
+    def _reverse_step(self, denoise_fn, x_t, x_in, y_in, step, cfg, noise, use_ddim, clip, want_pred, x_next, x_dup):
         B, C = x_t.shape[:2]
         HW = x_t[0, 0].numel()
+        k8, t_net = self._step_coefs(step, use_ddim)
+        t_in = torch.full((x_in.shape[0],), t_net, dtype=F64, device=x_t.device)
         out = denoise_fn(x_in, t_in, y_in).to(torch.float32).contiguous()
-        k8 = self._step_coefs(step, use_ddim)
         mot = _hip.OUT_TYPES[self.model_out_type]
         pred = None
         if want_pred:                                          # guided x0 prediction = the step-0 rule without noise
@@ -442,13 +575,12 @@ class GaussianDiffusion:
         """One reverse step (reference :360-392).  ``step`` is the (B,) tensor the reference passes; all entries must be
         equal (they are in ``p_sample``), which lets the host pre-compute the fp64 coefficients."""
         _need_cuda(x_t, "p_sample_step")
-        ti = int(step.reshape(-1)[0].item())
+        step = torch.as_tensor(step, device=x_t.device).reshape(-1)
+        ti = int(step[0].item())
         if not bool((step == ti).all()):
-            raise NotImplementedError("per-sample step indices are not supported by the fused sampler step")
-        B = x_t.shape[0]
+            return self._p_sample_step_per_sample(denoise_fn, x_t, step, y, generator, clip_denoised, return_pred, use_ddim)
         x_t = x_t.to(torch.float32).contiguous()
         cfg = self._use_cfg(y)
-        t = torch.full((B * (1 + cfg),), (ti + 1) / self.sample_timesteps, dtype=F64, device=x_t.device)
         if cfg:
             x_in = x_t.repeat_interleave(2, dim=0)
             y_in = y.repeat_interleave(2, dim=0).clone()
@@ -457,8 +589,39 @@ class GaussianDiffusion:
             x_in, y_in = x_t, y
         noise = torch.empty_like(x_t).normal_(generator=generator)
         x_next = torch.empty_like(x_t)
-        pred = self._reverse_step(denoise_fn, x_t, x_in, t, y_in, ti, cfg, noise, use_ddim, clip_denoised, return_pred, x_next, None)
+        pred = self._reverse_step(denoise_fn, x_t, x_in, y_in, ti, cfg, noise, use_ddim, clip_denoised, return_pred, x_next, None)
         return (x_next, pred) if return_pred else x_next
+
+    def _p_sample_step_per_sample(self, denoise_fn, x_t, step, y, generator, clip_denoised, return_pred, use_ddim):
+        """A (B,) step tensor with DIFFERENT entries (reference :360-392 accepts one): every sample has its own log-SNR pair,
+        so the host cannot hand the fused kernel one coefficient set; the step is composed from the per-sample posterior
+        API (``p_mean_var`` on (B,1,1,1) log-SNR tensors, device tensor ops) around the same HIP UNet forward.  The
+        samplers never take this branch (their step index is uniform)."""
+        T = self.sample_timesteps
+        x_t = x_t.to(torch.float32)
+        s, t = step.to(F64) / T, (step.to(F64) + 1) / T
+        logsnr_s, logsnr_t = self.t2logsnr(s, t, x=x_t)          # may rescale s, t in place, as the reference does
+        cond = (step > 0).reshape((-1,) + (1,) * (x_t.ndim - 1))
+        cfg = self._use_cfg(y)
+        rep = (lambda a: repeat_along_dim(a, 2)) if cfg else (lambda a: a)
+        x_in, t_in, y_in = rep(x_t), rep(t), (rep(y) if y is not None else None)
+        if cfg:
+            y_in = y_in.clone()
+            y_in[1::2] = 0
+        out = denoise_fn(x_in, t_in, y_in)
+        mean, logvar, pred = self.p_mean_var(out, x_in, rep(logsnr_s), rep(logsnr_t), clip_denoised=clip_denoised,
+                                             return_pred=True, use_ddim=use_ddim)
+        mean = torch.where(rep(cond), mean, pred)
+        if cfg:
+            mean, mean_u = slice_along_batch(mean, 2)
+            pred, pred_u = slice_along_batch(pred, 2)
+            mean = mean + self.w_guide * (mean - mean_u)
+            pred = pred + self.w_guide * (pred - pred_u)
+            if logvar.ndim > 0:
+                logvar = logvar[0::2]
+        noise = torch.empty_like(mean).normal_(generator=generator)
+        sample = mean + cond.to(mean.dtype) * torch.exp(0.5 * logvar) * noise
+        return (sample, pred) if return_pred else sample
 
     # ---- HIP-graph sampler (SURVEY 8f rank 2): the whole reverse step -- UNet forward + fused update -- captured once
     # into a HIP graph and replayed; per-step scalars live in a device buffer (k8), the state is updated in place, and
@@ -510,15 +673,16 @@ class GaussianDiffusion:
             st["xin"].copy_(x_t.repeat_interleave(2, dim=0))
         if y_in is not None:
             st["y"].copy_(y_in)
-        rowsk = []
+        rowsk, tnets = [], []
         for ti in range(T):
-            k8 = self._step_coefs(ti, use_ddim)
+            k8, t_net = self._step_coefs(ti, use_ddim)
             if ti == 0:                                # last step returns the x0 prediction: mean = 0*x_t + 1*x0_hat, no noise
                 k8[3], k8[4], k8[5] = 0.0, 1.0, 0.0
             rowsk.append(k8)
+            tnets.append(t_net)
         ktab = torch.tensor(rowsk, dtype=torch.float32).to(device)
         for ti in reversed(range(T)):
-            st["t"].fill_((ti + 1) / T)
+            st["t"].fill_(tnets[ti])
             st["noise"].normal_(generator=generator)
             st["k"].copy_(ktab[ti])
             graph.replay()
@@ -563,10 +727,9 @@ class GaussianDiffusion:
 
     def _eager_chain(self, denoise_fn, x_t, x_in, x_in_next, x_next, y_in, cfg, B, T, device, generator, use_ddim, pred_freq, preds):
         for ti in reversed(range(T)):
-            t_in = torch.full((B * (1 + cfg),), (ti + 1) / T, dtype=F64, device=device)
             step_noise = torch.empty_like(x_t).normal_(generator=generator)      # drawn every step, also for DDIM (:389)
             want = pred_freq is not None and (ti + 1) % pred_freq == 0
-            pred = self._reverse_step(denoise_fn, x_t, x_in if cfg else x_t, t_in, y_in, ti, cfg, step_noise, use_ddim, True,
+            pred = self._reverse_step(denoise_fn, x_t, x_in if cfg else x_t, y_in, ti, cfg, step_noise, use_ddim, True,
                                       want, x_next, x_in_next)
             if want:
                 preds.append(pred.cpu())
@@ -575,18 +738,46 @@ class GaussianDiffusion:
                 x_in, x_in_next = x_in_next, x_in
         return x_t, preds
 
+    @staticmethod
+    def _default_device(denoise_fn):
+        """device of the network's parameters (the reference defaults to "cpu", :398, which cannot run here)"""
+        net = getattr(denoise_fn, "module", denoise_fn)
+        if isinstance(net, torch.nn.Module):
+            for q in net.parameters():
+                return q.device
+        return torch.device("cuda")
+
     @torch.inference_mode()
-    def p_sample(self, denoise_fn, shape, noise=None, label=None, device="cuda", seed=None, use_ddim=False, use_graph=None):
-        """Full reverse chain (reference :394-414); returns a CPU tensor like the reference.  ``use_graph`` (extension):
-        True replays one captured HIP graph per reverse step (see _sample_loop_graph); default eager."""
+    def p_sample(self, denoise_fn, shape, noise=None, label=None, device=None, seed=None, use_ddim=False, use_graph=None):
+        """Full reverse chain (reference :394-414); returns a CPU tensor like the reference.  ``device=None`` (default)
+        = the device of ``denoise_fn``'s parameters (documented deviation: the reference's default "cpu" has no path here).
+        ``use_graph`` (extension): True replays one captured HIP graph per reverse step (see _sample_loop_graph)."""
+        device = self._default_device(denoise_fn) if device is None else device
         with _device_ctx(device):
             x, _ = self._sample_loop(denoise_fn, tuple(shape), noise, label, device, seed, use_ddim, use_graph=use_graph)
         return x.cpu()
 
     @torch.inference_mode()
-    def p_sample_progressive(self, denoise_fn, shape, noise=None, label=None, device="cuda", seed=None, use_ddim=False,
+    def p_sample_uint8_async(self, denoise_fn, shape, noise=None, label=None, device=None, seed=None, use_ddim=False,
+                             use_graph=None):
+        """The sampler plumbing of reference generate.py:143-150 without its host round trips: the chain
+        runs as in ``p_sample``; the result is quantised to uint8 and packed NCHW -> NHWC on the device
+        (``(x*127.5+127.5).clamp(0,255).to(uint8).permute(0,2,3,1)`` as one kernel, 4x fewer bytes over PCIe) and copied
+        into pinned host memory on a side stream.  Returns a ``PendingImages``: the call does not block, so the next
+        batch's chain is enqueued while this copy drains; ``.numpy()`` waits for the copy only."""
+        device = torch.device(self._default_device(denoise_fn) if device is None else device)
+        with _device_ctx(device):
+            x, _ = self._sample_loop(denoise_fn, tuple(shape), noise, label, device, seed, use_ddim, use_graph=use_graph)
+            B, C, Hh, Ww = x.shape
+            u8 = torch.empty((B, Hh, Ww, C), dtype=torch.uint8, device=device)
+            _hip.images_to_uint8_hwc(x.contiguous(), u8, B, C, Hh * Ww)
+            return PendingImages(u8)
+
+    @torch.inference_mode()
+    def p_sample_progressive(self, denoise_fn, shape, noise=None, label=None, device=None, seed=None, use_ddim=False,
                              pred_freq=50):
         """reference :416-441: also returns the x0 predictions every ``pred_freq`` steps (earliest step first)."""
+        device = self._default_device(denoise_fn) if device is None else device
         with _device_ctx(device):
             x, preds = self._sample_loop(denoise_fn, tuple(shape), noise, label, device, seed, use_ddim, pred_freq)
         L = self.sample_timesteps // pred_freq

@@ -299,6 +299,12 @@ class UNetEngine:
                 self._linear_bwd(yn, m.class_embed.weight, dte, G["class_embed.weight"], G["class_embed.bias"], None)
             else:
                 H.class_embed_bwd(yn, dte, G["class_embed.1.weight"], G["class_embed.1.bias"], B, m.embedding_dim, m.num_classes)
+        elif m.num_classes:
+            # class-conditional network called without labels: the reference leaves these gradients None and its optimizer
+            # skips them; every entry of G must be written (flat buffers are reused across steps), so they are exact zeros
+            for k in G:
+                if k.startswith("class_embed."):
+                    G[k].zero_()
         l0, l2 = m.time_embed[0], m.time_embed[2]
         da0 = torch.empty_like(dte)
         self._linear_bwd(a0, l2.weight, dte, G["time_embed.2.weight"], G["time_embed.2.bias"], da0)

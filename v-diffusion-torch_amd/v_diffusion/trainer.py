@@ -192,7 +192,11 @@ class HotPathTrainer:
                 decay = min(self.ema_decay, (1 + flat.ema_updates) / (10 + flat.ema_updates))   # utils.py:145-146
             _hip.adamw_ema(flat.p, flat.g, flat.m, flat.v, flat.ema, flat.gnorm_sq, float(self.grad_norm), lr, self.betas[0],
                            self.betas[1], self.eps, self.wd, 1 - self.betas[0] ** k, 1 - self.betas[1] ** k, decay)
-        return loss.detach()
+        loss = loss.detach()
+        if self.world > 1:                                         # train_utils.py:156-158: the leader reports the rank mean
+            dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM, group=self.reducer.group)
+            loss.div_(self.world)
+        return loss
 
     # ------------------------------------------------------------------ EMA weights for sampling (utils.py:151-166)
     def ema_weights(self):
@@ -233,11 +237,24 @@ class HotPathTrainer:
                             "_get_lr_called_within_step": False, "_last_lr": [self._lr_now()], "lr_lambdas": [None]}
         return out
 
+    def gather_rng_states(self):
+        """{rank: generator state} of EVERY rank (train_utils.py:277-291: all_gather as int64 on the device, back to uint8);
+        a collective when world_size > 1 -- all ranks must call it."""
+        state = self.generator.get_state()
+        if self.world == 1:
+            return {self.rank: state}
+        mine = state.to(torch.int64).to(self.device)
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.reducer.group)
+        return {r: q.cpu().to(torch.uint8) for r, q in enumerate(parts)}
+
     def save_checkpoint(self, path, **extra):
+        """All ranks call this (the generator states are gathered); only the leader (rank 0) writes the file."""
         ckpt = self.state_dicts()
-        ckpt["rng"] = {self.rank: self.generator.get_state()}
+        ckpt["rng"] = self.gather_rng_states()
         ckpt.update(extra)
-        torch.save(ckpt, path)
+        if self.rank == 0 or self.world == 1:
+            torch.save(ckpt, path)
 
     def load_checkpoint(self, path_or_dict, map_location=None):
         """Reads a checkpoint written by the reference ``Trainer.save_checkpoint`` (or by ``save_checkpoint`` above):
@@ -283,8 +300,13 @@ class HotPathTrainer:
             sch = ckpt.get("scheduler")
             if sch is not None and opt is None:
                 flat.step_count = int(sch.get("last_epoch", flat.step_count))
-        if "rng" in ckpt and ckpt["rng"] is not None and int(self.rank) in ckpt["rng"]:
-            self.generator.set_state(ckpt["rng"][int(self.rank)].cpu())
+        if ckpt.get("rng") is not None:
+            if int(self.rank) in ckpt["rng"]:
+                self.generator.set_state(ckpt["rng"][int(self.rank)].cpu())
+            else:
+                import warnings
+                warnings.warn(f"checkpoint holds no generator state for rank {self.rank} (has {sorted(ckpt['rng'])}): this rank "
+                              f"continues from its fresh seed and will replay the t/noise stream it drew before the checkpoint")
         return ckpt.get("epoch", 0)
 
 
