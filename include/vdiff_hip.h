@@ -81,6 +81,23 @@ int vd_conv3x3(const float* xin, int64_t ldx, const float* wpack, const float* b
                int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t accumulate,
                float* stats_part /* optional: GroupNorm partials of y, see vd_gemm_desc.stats */, void* stream);
 
+/* The same convolution as Winograd F(2x2,3x3) on the fp32 matrix cores (csrc/wino.hip): 2.25x fewer MFMA cycles, exact fp32
+ * arithmetic, input/output transforms fused into the tile loads / the epilogue (nothing but x, U, y touches HBM).
+ *   U = vd_wino_pack(w): uf[16][Cout][Cin] for the forward pass, ud[16][Cin][Cout] (rotated kernel) for the input gradient
+ *   (the input gradient of modules.py:141-144 is the same call with xin = dy, U = ud, Cin <-> Cout).
+ * vd_conv3x3_wino_supported: 1 when the geometry is served (H, W even powers of two with 4 <= W/2 <= 64, H*W/4 >= 16 tiles per
+ * image, Cin % 16 == 0, Cout % 4 == 0, tensors < 2 GiB); otherwise call vd_conv3x3.  stats_part as in vd_conv3x3 with 64-pixel
+ * chunks ([img][H*W/64][2][Cout]); vd_gemm_last_tile() reports BM = 128 for it so chunk = BM/2 holds for both paths. */
+int vd_conv3x3_wino_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t ldy, int64_t ldres);
+int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, const float* bias, const float* res, int64_t ldres,
+                    float* y, int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                    float* stats_part, void* stream);
+/* diagnostics: per-wave phase timestamps of the next vd_conv3x3_wino launches into buf (32 x uint64 per workgroup), NULL = off */
+int vd_wino_set_probe(unsigned long long* buf);
+int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
+/* all 3x3 kernels of a network in one launch: items_dev = [n][8] int64 {w, uf, ud, Cout, Cin, 0, 0, first 256-thread block} */
+int vd_wino_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
+
 /* "thin" 3x3 convolutions (3-4 channels on one side: in_conv unet.py:217, out_conv :232).  The taps are moved to the thin
  * side so that the wide side is a plain vd_gemm instead of an implicit GEMM with a 64-wide tile on 3 useful columns:
  *   thin input :  xc = vd_im2col3x3(x) [pixels][9*C]            then  y = vd_gemm(xc, wpack[Cout][9*C])  (+ its transposes)

@@ -1,0 +1,39 @@
+"""Where a Winograd workgroup spends its cycles (vd_wino_set_probe): prologue / K loop / epilogue, cycles parked at the K-tile
+barrier, first K tile.  python tests/probe/wino_phases.py"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "v-diffusion-torch_amd"))
+from v_diffusion import _hip as H
+
+DEV = "cuda"
+for nimg, Hh, Ww, Cin, Cout, stats in ((128, 32, 32, 256, 256, False), (128, 32, 32, 256, 256, True), (128, 16, 16, 512, 256, False)):
+    x = torch.randn(nimg, Hh, Ww, Cin, device=DEV)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) * (9 * Cin) ** -0.5
+    uf = torch.empty(16, Cout, Cin, device=DEV)
+    H.wino_pack(w, Cout, Cin, uf=uf)
+    y = torch.empty(nimg, Hh, Ww, Cout, device=DEV)
+    res = torch.randn_like(y)
+    b = torch.randn(Cout, device=DEV)
+    part = torch.empty(H.stats_part_numel(nimg, Hh * Ww, Cout), device=DEV)
+    nwg = (Cout // 32) * (nimg * Hh * Ww // 4 // 64)
+    buf = torch.zeros(nwg * 64, dtype=torch.int64, device=DEV)
+    for _ in range(3):
+        H.conv3x3_wino(x, Cin, uf, b if stats else None, y, Cout, nimg, Hh, Ww, Cin, Cout, res=res if stats else None, ldres=Cout,
+                       stats_part=part if stats else None)
+    H.lib().vd_wino_set_probe(buf.data_ptr())
+    H.conv3x3_wino(x, Cin, uf, b if stats else None, y, Cout, nimg, Hh, Ww, Cin, Cout, res=res if stats else None, ldres=Cout,
+                   stats_part=part if stats else None)
+    torch.cuda.synchronize()
+    H.lib().vd_wino_set_probe(None)
+    t = buf.view(nwg, 8, 8).double().cpu()
+    pro, loop, epi, wait, first, nkt = (t[..., 1] - t[..., 0]), (t[..., 2] - t[..., 1]), (t[..., 3] - t[..., 2]), t[..., 4], t[..., 5], t[..., 6]
+    rt = t[..., 7]
+    print(f"{nimg}x{Hh}x{Ww} {Cin}->{Cout} stats={stats}: workgroups {nwg}, K tiles {int(nkt.max())}")
+    print(f"  cycles per wave (median): prologue {pro.median():.0f}  loop {loop.median():.0f} ({loop.median() / nkt.max():.0f} per K tile)  "
+          f"epilogue {epi.median():.0f}  parked at the tile barrier {wait.median():.0f} ({100 * wait.median() / loop.median():.1f} % of the loop)  "
+          f"first tile {first.median():.0f}")
+    print(f"  span of workgroup end times: {(rt.max() - rt.min()) / 100:.1f} us (100 MHz clock)")

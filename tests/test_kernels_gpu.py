@@ -678,3 +678,74 @@ def test_kernel_variants_in_subprocess(H, knobs):
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) convolution
+WINO_CASES = [  # nimg, H, W, Cin, Cout, ldx_extra, ldy_extra      (geometries: every patch-image variant of csrc/wino.hip)
+    (2, 32, 32, 64, 64, 0, 0),       # 16 tiles per row: one workgroup = 4 tile rows of one image
+    (3, 16, 16, 32, 96, 32, 64),     # 8 tiles per row, one image per workgroup, ld > C on both sides, partial 2nd channel block
+    (5, 8, 8, 48, 36, 0, 4),         # 4 tiles per row: 4 images per workgroup, last workgroup has 1 valid image, Cout % 32 != 0
+    (1, 64, 64, 16, 32, 0, 0),       # 32 tiles per row: half a tile row per wave
+    (2, 16, 32, 32, 32, 0, 0),       # non-square
+    (1, 8, 128, 16, 20, 0, 0),       # 64 tiles per row (largest patch image)
+    (4, 32, 32, 256, 256, 0, 0), (8, 16, 16, 512, 256, 0, 0), (16, 8, 8, 256, 256, 0, 0), (1, 64, 64, 192, 192, 0, 0)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_wino_forward_stats_dgrad(H, case):
+    """vd_conv3x3_wino == F.conv2d (+bias +residual), its GroupNorm partial sums == statistics of the output, and the same
+    kernel on the rotated pack == the input gradient.  Error budget: Winograd F(2x2,3x3) in fp32 carries ~2x the rounding error
+    of a direct fp32 sum (measured against fp64), so the slack over torch's own fp32 result is 8 instead of 4."""
+    nimg, Hh, Ww, Cin, Cout, ex, ey = case
+    assert H.lib().vd_conv3x3_wino_supported(nimg, Hh, Ww, Cin, Cout, Cin + ex, Cout + ey, Cout + ey) == 1
+    x, w, b = rnd(nimg, Cin, Hh, Ww, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=3)
+    res = rnd(nimg, Cout, Hh, Ww, seed=4)
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    ref32 = F.conv2d(x, w, b, padding=1) + res
+    xd, rd = nhwc(x, Cin + ex), nhwc(res, Cout + ey)
+    uf, ud = torch.empty(16, Cout, Cin, device=DEV), torch.empty(16, Cin, Cout, device=DEV)
+    H.wino_pack(w.to(DEV), Cout, Cin, uf=uf, ud=ud)
+    y = torch.full((nimg, Hh, Ww, Cout + ey), 5.0, device=DEV)
+    HW = Hh * Ww
+    part = torch.full((H.stats_part_numel(nimg, HW, Cout),), 7.0, device=DEV)
+    H.conv3x3_wino(xd, Cin + ex, uf, b.to(DEV), y, Cout + ey, nimg, Hh, Ww, Cin, Cout, res=rd, ldres=Cout + ey, stats_part=part)
+    torch.cuda.synchronize()
+    close(from_nhwc(y, Cout), ref64, ref32, slack=8.0, floor=4e-6, name="wino fwd")
+    if ey:
+        assert (y[..., Cout:] == 5.0).all(), "padding channels of the output were written"
+    assert H.last_row_tile() == 128
+    if Cout % 32 == 0:
+        stats = torch.empty(nimg, 32, 2, device=DEV)
+        H.gn_stats_from_partials([(part, Cout, HW // 64)], nimg, HW, stats)
+        g = ref64.reshape(nimg, 32, -1)
+        close(stats[..., 0], g.mean(-1), None, floor=4e-6, name="wino stats mean")
+        close(stats[..., 1], 1 / torch.sqrt(g.var(-1, unbiased=False) + 1e-6), None, floor=1e-5, name="wino stats rstd")
+    # without statistics / residual / bias: bitwise the same convolution result
+    y2 = torch.empty(nimg, Hh, Ww, Cout, device=DEV)
+    H.conv3x3_wino(xd, Cin + ex, uf, None, y2, Cout, nimg, Hh, Ww, Cin, Cout)
+    y3 = torch.empty_like(y2)
+    H.conv3x3_wino(xd, Cin + ex, uf, None, y3, Cout, nimg, Hh, Ww, Cin, Cout)
+    assert torch.equal(y2, y3)
+    close(from_nhwc(y2, Cout), F.conv2d(x.double(), w.double(), padding=1), F.conv2d(x, w, padding=1), slack=8.0, floor=4e-6, name="wino plain")
+    # input gradient: the same kernel on ud with the channel roles swapped
+    if Cout % 16 == 0 and Cin % 4 == 0:
+        dy = rnd(nimg, Cout, Hh, Ww, seed=5)
+        x64 = x.double().requires_grad_(True)
+        F.conv2d(x64, w.double(), padding=1).backward(dy.double())
+        x32 = x.clone().requires_grad_(True)
+        F.conv2d(x32, w, padding=1).backward(dy)
+        dx = torch.empty(nimg, Hh, Ww, Cin, device=DEV)
+        H.conv3x3_wino(nhwc(dy), Cout, ud, None, dx, Cin, nimg, Hh, Ww, Cout, Cin)
+        torch.cuda.synchronize()
+        close(from_nhwc(dx, Cin), x64.grad, x32.grad, slack=8.0, floor=4e-6, name="wino dgrad")
+
+
+def test_conv3x3_wino_rejects_unsupported(H):
+    f = H.lib().vd_conv3x3_wino_supported
+    assert f(2, 4, 4, 32, 32, 32, 32, 0) == 0            # 2 tiles per row
+    assert f(2, 16, 16, 24, 32, 24, 32, 0) == 0          # Cin % 16
+    assert f(2, 12, 16, 32, 32, 32, 32, 0) == 0          # H/2 not a power of two
+    assert f(2, 16, 16, 32, 32, 32, 32, 0) == 1
+    x = torch.zeros(2, 4, 4, 32, device=DEV)
+    with pytest.raises(H.HipError, match="unsupported geometry"):
+        H.conv3x3_wino(x, 32, torch.zeros(16, 32, 32, device=DEV), None, torch.empty_like(x), 32, 2, 4, 4, 32, 32)

@@ -990,7 +990,6 @@ __global__ void pack_conv3x3_batched_kernel(const long long* items, int n) {
     }
 }
 
-thread_local int g_last_tile = 0;
 
 bool use_dma(const GemmArgs& a) {
     static const bool legacy = getenv("VD_GEMM_LEGACY") != nullptr;       // A/B switch for profiling
@@ -1067,7 +1066,7 @@ void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     constexpr bool has16 = BM == 128 && BN == 128 && !(BK == VD_IM2COL && !SPLITK);
     const bool k16 = has16 && ktile == 16;
     const bool tr = use_dma(a) && use_tr(a, BK == VD_IM2COL);
-    g_last_tile = ((((tr ? 1 : 0) * 100 + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
+    vd_g_last_tile = ((((tr ? 1 : 0) * 100 + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
     else if (k16 && tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true>), grid, dim3(256), 0, st, a);
     else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false>), grid, dim3(256), 0, st, a);
@@ -1180,7 +1179,8 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int vd_gemm_last_tile(void) { return g_last_tile; }
+thread_local int vd_g_last_tile = 0;
+extern "C" int vd_gemm_last_tile(void) { return vd_g_last_tile; }
 
 extern "C" int vd_gemm(const vd_gemm_desc* d, void* stream) {
     VD_REQUIRE(d != nullptr, "vd_gemm: null descriptor");

@@ -1,0 +1,516 @@
+// wino.hip -- 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix cores, NHWC.
+// Reference op: modules.Conv2d -> F.conv2d (modules.py:141-144 <- unet.py:121,125) and its input gradient (autograd).
+//
+// Why: 3x3 convolutions are 87-91 % of the FLOPs of the path and gfx950 has no reduced-precision fast path
+// for fp32 inputs (v_mfma_f32_* runs at the fp32 vector rate), so the direct implicit GEMM is pinned under 157 TFLOP/s.
+// F(2x2,3x3) needs 16 multiplies per 2x2 output tile and (ci, co) pair instead of 36: 2.25x fewer matrix-core cycles for
+// the same result in exact fp32 arithmetic (max error ~2x the direct form's, measured against fp64: tests).
+//
+//   U[xi][co][ci]   = (G w[co][ci] G^T)[xi]                       xi = 4a+b in 0..15      (vd_wino_pack*, once per weight update)
+//   V[xi][t][ci]    = (B^T d[t][ci] B)[xi]                        d = 4x4 input patch of 2x2-output tile t   (on the fly)
+//   M[xi][t][co]    = sum_ci V[xi][t][ci] U[xi][co][ci]           16 independent GEMMs                         (MFMA)
+//   y[t][u][v][co]  = (A^T M[.][t][co] A)[u][v] + bias + residual                                           (epilogue)
+//
+// Everything between the NHWC input and the NHWC output stays on chip (V and M never exist in HBM):
+//   * workgroup = 4 waves = 64 consecutive tiles x 32 output channels x all 16 xi; wave w owns tiles 16w..16w+15 and ALL 16 xi,
+//     so the output transform is lane-local (no cross-wave exchange): v_mfma_f32_16x16x4_f32 with U as the row operand gives
+//     lane (i, rq) the four consecutive channels 4rq..4rq+3 of tile i in one accumulator quad per xi;
+//   * per K tile (16 input channels) the raw input patch (not V: 4x fewer bytes) and the 16 U tiles go HBM/L2 -> LDS with
+//     `buffer_load_dwordx4 ... lds`.  The patch image is chunk-major with odd and even input columns in separate runs, so that
+//     the 16 tiles of a wave read 16 consecutive 16-byte slots for every patch position (conflict-free ds_read_b128);
+//     the U image is [xi][co][16 k] with the chunk XOR-swizzled by (co >> 2) & 2 (conflict-free for the 16x16x4 lane map);
+//   * a lane reads its 4x4 patch (16 x b128 = 4 channels each), applies B^T . B in registers (32 adds per channel) and feeds
+//     128 MFMAs per K tile; the patch of K tile t+1 is read from LDS while tile t computes (the patch stream runs one tile ahead
+//     of the U stream, one barrier per K tile);
+//   * epilogue: A^T . A in registers (24 adds per output quad), bias, residual, dwordx4 stores, optional GroupNorm partial sums
+//     of the output (16-lane butterflies) in the layout vd_gn_stats_from_partials expects (chunk = the wave's 64 pixels).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB = 0x80000000u;
+constexpr int KT = 16;            // input channels per K tile (one ds_read_b128 per lane and operand)
+constexpr int TN = 32;            // output channels per workgroup
+constexpr int TILES_WG = 64;      // 2x2-output tiles per workgroup (16 per wave)
+constexpr int B_STAGE = 16 * TN * KT;          // floats of U per stage (32 KB)
+
+struct WinoArgs {
+    const float* x; long long ldx;             // input  [nimg][H][W][>=K]
+    const float* U;                            // [16][Cout][K]
+    const float* bias; const float* res; long long ldr;
+    float* y; long long ldy;
+    float* stats;                              // optional GroupNorm partials [img][HW/64][2][Cout]
+    int nimg, H, W, K, Cout;
+    int TW, TH, TPI;                           // tiles per row / column / image
+    int P;                                     // patch-image row pitch in slots
+    int RIN;                                   // input rows per image held by a workgroup (2*tile_rows + 2)
+    int NTR;                                   // tile rows per image per workgroup
+    int NIW;                                   // images per workgroup (1 unless an image has fewer than 64 tiles)
+    int lgTW, lgTPI;                           // log2 (all supported geometries are powers of two)
+    float invP2, invRIN;                       // 1 / (2 P), 1 / RIN (prologue index arithmetic without integer division)
+    int ntiles;                                // nimg * TPI
+    unsigned long long* probe;                 // timing probe build only (vd_wino_set_probe): 8 x u64 per workgroup
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
+}
+
+__device__ __forceinline__ int b_swz(int row) { return (row >> 2) & 2; }
+
+// NS = patch slots per 16-byte channel chunk (multiple of 128); STATS = emit GroupNorm partial sums.
+// 8 waves (two per SIMD: with one, the wave's own LDS / DMA / transform instructions sit between its MFMAs -- 59 cycles per MFMA
+// instead of 32 in the first version of this kernel): wave w owns tile group w & 3 (16 tiles) and HALF of the xi range,
+// a in {2h, 2h+1} with h = w >> 2, for both channel blocks.  Splitting xi (not channels) between the two waves of a tile group
+// means neither repeats the other's input transform: each needs three of the four patch rows and half of the B^T . B work.
+// Their partial output transforms meet once, through LDS, in the epilogue.
+template <int NS, bool STATS, bool PROBE = false>
+__global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, tfirst = 0;
+    if (PROBE) ts0 = __builtin_amdgcn_s_memtime();
+    constexpr int A_STAGE = 4 * NS * 4;                 // floats: 4 chunks x NS slots x 4 floats
+    constexpr int NPA = 4 * NS / 64;                    // DMA pieces (1 KiB) of a patch stage
+    constexpr int NPB = B_STAGE / 256;                  // 32 pieces of a U stage
+    constexpr int APW = NPA / 8, BPW = NPB / 8;         // pieces per wave
+    static_assert(NS % 128 == 0, "patch slots per chunk must give every wave whole DMA pieces");
+    __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE];
+    float* const sA = smem;
+    float* const sB = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int tg = wave & 3, ah = wave >> 2;           // tile group, xi half
+
+    // XCD-aware order (see gemm.hip): each XCD walks a contiguous range of (tile group, channel block) pairs, channel blocks
+    // fastest, so the workgroups that share an input patch run on one L2
+    int tbx = blockIdx.x, tby = blockIdx.y;
+    {
+        const unsigned T = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (T >= 16) {
+            const unsigned q = T / 8, r = T % 8, xcd = lin % 8, slot = lin / 8;
+            const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+            tbx = t % gridDim.x; tby = t / gridDim.x;
+        }
+    }
+    const int co0 = tbx * TN;
+    const int tile0 = tby * TILES_WG;                               // first tile of the workgroup
+    const int img0 = tile0 >> p.lgTPI;                              // first image
+    const int trow0 = (tile0 & (p.TPI - 1)) >> p.lgTW;              // first tile row inside it (0 when a workgroup spans images)
+    const int y_first = 2 * trow0 - 1;                              // input row held in local row 0 of every image of the workgroup
+
+    // ---------------- DMA source offsets (bytes, constant over the K loop; the channel advance lives in the descriptor base)
+    unsigned voA[APW], voB[BPW];
+    {
+        const int P2 = 2 * p.P;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int q = wave + 8 * j;                             // piece id
+            const int chunk = q / (NS / 64);
+            const int s = (q % (NS / 64)) * 64 + lane;              // slot inside the chunk
+            int rr = (int)((float)s * p.invP2);                     // s / P2 (s < 1024: one correction step is enough)
+            if (rr * P2 > s) --rr; else if ((rr + 1) * P2 <= s) ++rr;
+            const int rem = s - rr * P2;                            // position in the (odd, even) row pair
+            const int par = rem >= p.P ? 1 : 0, idx = rem - par * p.P;
+            int il = (int)((float)rr * p.invRIN);                   // local image, row inside it
+            if (il * p.RIN > rr) --il; else if ((il + 1) * p.RIN <= rr) ++il;
+            const int r = rr - il * p.RIN;
+            const int yy = y_first + r, xx = 2 * idx - 1 + par;     // par 0: odd columns x = 2 idx - 1 ; par 1: even columns x = 2 idx
+            const int img = img0 + il;
+            unsigned vo = OOB;
+            if (il < p.NIW && img < p.nimg && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                vo = (unsigned)((((long long)img * p.H + yy) * p.W + xx) * p.ldx + chunk * 4) * 4u;
+            voA[j] = vo;
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int q = wave + 8 * j;                             // piece = (xi, half): 16 rows x 64 B
+            const int xi = q >> 1, half = q & 1;
+            const int row = lane >> 2, c = (lane & 3) ^ b_swz(row);
+            const int co = co0 + half * 16 + row;
+            voB[j] = co < p.Cout ? (unsigned)(((long long)xi * p.Cout + co) * p.K + c * 4) * 4u : OOB;
+        }
+    }
+    // DMA of K tile kt into stage `buf`; past the K range every lane's offset is out of range (the DMA then writes zeros into a
+    // stage nobody reads), so the issue is branch-free and the loop body stays one basic block
+    auto issue_A = [&](int kt, int buf, bool live) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT, live ? (int)OOB : 0);
+        float* dst = sA + buf * A_STAGE;
+#pragma unroll
+        for (int j = 0; j < APW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (wave + 8 * j) * 256), 16, (int)voA[j], 0, 0, 0);
+    };
+    auto issue_B = [&](int kt, int buf, bool live) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.U + kt * KT, live ? (int)OOB : 0);
+        float* dst = sB + buf * B_STAGE;
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (wave + 8 * j) * 256), 16, (int)voB[j], 0, 0, 0);
+    };
+
+    // ---------------- this lane's tile and its patch base slot
+    const int tl = 16 * tg + li;                                    // tile inside the workgroup
+    const int tile = tile0 + tl;
+    const int il = tl >> p.lgTPI;                                   // local image (0 unless the workgroup spans images)
+    const int tin = (tile & (p.TPI - 1));                           // tile inside its image
+    const int ty = tin >> p.lgTW, tx = tin & (p.TW - 1);
+    const int slot0 = ((il * p.RIN + 2 * (ty - trow0)) * 2) * p.P + tx;      // slot of patch position (p=0, q=0), chunk 0
+    // this wave's xi half needs patch rows ah .. ah+2:  a=0: p0-p2, a=1: p1+p2 | a=2: p2-p1, a=3: p1-p3
+    const float* patch_base = sA + (lq * NS + slot0 + ah * 2 * p.P) * 4;     // + chunk lq, first needed row
+    int poff[3][4];                                                 // float offsets of the 12 patch positions
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) poff[pr][q] = ((pr * 2 + (q & 1)) * p.P + (q >> 1)) * 4;
+
+    // the two rows of B^T this wave owns, applied over the patch row index: L[0..2] -> tr[0..1]
+    auto row_transform = [&](const f32x4 (&L)[3][4], f32x4 (&tr)[2][4]) {
+        if (ah == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tr[0][q] = L[0][q] - L[2][q]; tr[1][q] = L[1][q] + L[2][q]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tr[0][q] = L[1][q] - L[0][q]; tr[1][q] = L[0][q] - L[2][q]; }
+        }
+    };
+
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[xi][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / KT;
+    // U fragment of (xi, cb): lane (n = li, kq = lq) holds U[xi][co0 + 16 cb + n][k0 + 4 kq .. +3]
+    const int boff = ah * 8 * 2 * 256 + li * KT + ((lq ^ b_swz(li)) << 2);
+
+    // One K tile = 8 xi steps of 8 MFMAs per wave.  The LDS reads are software-pipelined by hand and pinned with
+    // sched_group_barrier (left alone, the scheduler sinks every fragment read to just in front of its first MFMA and the wave
+    // sits on lgkmcnt): step x issues the U fragments of step x + 2 and its share of the 12 patch reads of the NEXT K tile
+    // (3 LDS reads per step), then its own 8 MFMAs.
+    // The two waves of a SIMD (w and w + 4) would otherwise run in lockstep: both issue their DMA burst (7 pieces, ~100 cycles of
+    // issue each) right behind the barrier and the matrix pipe idles meanwhile.  Waves 0-3 issue theirs in front of the first
+    // half of the tile, waves 4-7 between the halves, so one of the two always has MFMAs to issue (in-kernel stamps: loop
+    // 6250 -> see DESIGN cycles per K tile).
+    f32x4 ub[3][2];
+    auto half = [&](const int a, int buf, const f32x4 (&tr)[2][4], f32x4 (&Ln)[3][4]) {
+        const float* bs = sB + buf * B_STAGE + boff;
+        const float* ps = patch_base + (buf ^ 1) * A_STAGE;
+        if (a == 0) {
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) ub[z][cb] = *reinterpret_cast<const f32x4*>(bs + (z * 2 + cb) * 256);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
+        f32x4 V[4];
+        V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xi = 4 * a + b;
+            if (xi < 6) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) ub[(xi + 2) % 3][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 2) * 2 + cb) * 256);
+                Ln[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4*>(ps + poff[xi >> 2][xi & 3]);         // patch reads 0..5
+            } else {
+#pragma unroll
+                for (int z = 0; z < 3; ++z) {                                                               // patch reads 6..11
+                    const int e = 6 + (xi - 6) * 3 + z;
+                    Ln[e >> 2][e & 3] = *reinterpret_cast<const f32x4*>(ps + poff[e >> 2][e & 3]);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][0][j], V[b][j], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][1][j], V[b][j], acc[xi][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+    };
+
+    // ---------------- main loop: the patch stream runs one K tile ahead of the U stream
+    f32x4 tr[2][4];
+    issue_A(0, 0, true);
+    issue_A(1, 1, nkt > 1);
+    issue_B(0, 0, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        f32x4 L[3][4];
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) L[pr][q] = *reinterpret_cast<const f32x4*>(patch_base + poff[pr][q]);
+        row_transform(L, tr);
+    }
+    if (PROBE) ts1 = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        // (patch kt was read out of sA[buf] during the previous iteration / the prologue; U of kt-1 in sB[buf^1] is dead since the barrier)
+        f32x4 Ln[3][4];                    // (the last iteration reads a dead patch stage into it: unused)
+        if (ah == 0) { issue_A(kt + 2, buf, kt + 2 < nkt); issue_B(kt + 1, buf ^ 1, kt + 1 < nkt); }
+        half(0, buf, tr, Ln);
+        if (ah != 0) { issue_A(kt + 2, buf, kt + 2 < nkt); issue_B(kt + 1, buf ^ 1, kt + 1 < nkt); }
+        half(1, buf, tr, Ln);
+        row_transform(Ln, tr);
+        unsigned long long tw = 0;
+        if (PROBE) tw = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (PROBE) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; if (kt == 0) tfirst = te - ts1; }
+    }
+    if (PROBE) ts2 = __builtin_amdgcn_s_memtime();
+
+    // ---------------- epilogue: y = A^T M A (+ bias + residual)      A^T = [1 1 1 0 ; 0 1 -1 -1]
+    // lane (li, lq): tile `tile`, channels co0 + 16 cb + 4 lq .. +3.  Column part in registers: s[a][v] = sum_b M[a][b] A[b][v];
+    // row part: Y[0][v] = s[0][v] + s[1][v] + s[2][v], Y[1][v] = s[1][v] - s[2][v] - s[3][v] -- this wave holds a in {2h, 2h+1},
+    // so it forms its partial P[u][v] of both channel blocks, hands the block it does not finish to its partner wave through
+    // LDS (wave h finishes channel block h) and adds the partner's partial to its own.
+    f32x4 P[2][2][2];                       // [cb][u][v]
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        f32x4 s0[2], s1[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const f32x4 t1 = acc[4 * a + 1][cb] + acc[4 * a + 2][cb], t2 = acc[4 * a + 1][cb] - acc[4 * a + 2][cb];
+            s0[a] = acc[4 * a][cb] + t1;
+            s1[a] = t2 - acc[4 * a + 3][cb];
+        }
+        if (ah == 0) { P[cb][0][0] = s0[0] + s0[1]; P[cb][0][1] = s1[0] + s1[1]; P[cb][1][0] = s0[1]; P[cb][1][1] = s1[1]; }
+        else { P[cb][0][0] = s0[0]; P[cb][0][1] = s1[0]; P[cb][1][0] = -s0[0] - s0[1]; P[cb][1][1] = -s1[0] - s1[1]; }
+    }
+    {
+        // exchange area (the stages are dead: the loop ended on a barrier): [wave][k = 2u+v][lane] float4
+        f32x4* xch = reinterpret_cast<f32x4*>(smem);
+        const int give = ah ^ 1;            // channel block handed to the partner
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) xch[(wave * 4 + 2 * u + v) * 64 + lane] = P[give][u][v];
+        __syncthreads();
+        const int partner = wave ^ 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) P[ah][u][v] += xch[(partner * 4 + 2 * u + v) * 64 + lane];
+    }
+    const bool tile_ok = tile < p.ntiles;
+    const int img = tile >> p.lgTPI;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const long long pix00 = ((long long)img * p.H + 2 * ty) * p.W + 2 * tx;
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
+    const int co = co0 + 16 * ah + 4 * lq;
+    const bool ok = tile_ok && co < p.Cout;                         // (Cout is a multiple of 4)
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ok) b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    f32x4 r4[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const unsigned vor = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldr + co) * 4) : OOB;
+            r4[u][v] = p.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const f32x4 val = (P[ah][u][v] + b4) + r4[u][v];
+            if (STATS) { a1 += val; a2 += val * val; }
+            const unsigned voc = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldy + co) * 4) : OOB;
+            const u32x4 w = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(w, yrs, (int)voc, 0, 0);
+        }
+    if (STATS) {
+        // sum over the wave's 16 tiles (= lanes with equal lq): fixed-order butterfly, then lane li = 0 writes its 4 channels of
+        // the [2][Cout] record of the wave's 64-pixel chunk
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v1 = a1[j], v2 = a2[j];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 16); v2 += __shfl_xor(v2, o, 16); }
+            a1[j] = v1; a2[j] = v2;
+        }
+        const int wtile = tile0 + 16 * tg;                          // the tile group's first tile: all 16 lie in one image
+        if (li == 0 && wtile < p.ntiles && co < p.Cout) {
+            const int wimg = wtile >> p.lgTPI, chunk = (wtile & (p.TPI - 1)) >> 4;
+            float* o = p.stats + ((long long)wimg * (p.TPI >> 4) + chunk) * 2 * p.Cout;
+            *reinterpret_cast<f32x4*>(o + co) = a1;
+            *reinterpret_cast<f32x4*>(o + p.Cout + co) = a2;
+        }
+    }
+    if (PROBE && p.probe) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* o = p.probe + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+            o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = twait; o[5] = tfirst; o[6] = (unsigned long long)nkt;
+            o[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+}
+
+// ---- weight transform: uf[xi][co][ci] = (G w[co][ci] G^T)[xi] ; ud[xi][ci][co] = (G rot180(w[co][ci]) G^T)[xi]
+// G = [1 0 0 ; .5 .5 .5 ; .5 -.5 .5 ; 0 0 1]
+__device__ __forceinline__ void g_transform(const float (&w)[3][3], float (&u)[4][4]) {
+    float t[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t[0][j] = w[0][j];
+        t[1][j] = 0.5f * (w[0][j] + w[1][j] + w[2][j]);
+        t[2][j] = 0.5f * (w[0][j] - w[1][j] + w[2][j]);
+        t[3][j] = w[2][j];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        u[a][0] = t[a][0];
+        u[a][1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        u[a][2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        u[a][3] = t[a][2];
+    }
+}
+
+__device__ __forceinline__ void wino_pack_one(const float* w, float* uf, float* ud, int Cout, int Cin, long long idx) {
+    if (idx >= (long long)Cout * Cin) return;
+    const int co = idx / Cin, ci = idx % Cin;
+    float k[3][3], u[4][4];
+    const float* src = w + idx * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) k[i][j] = src[i * 3 + j];
+    if (uf) {
+        g_transform(k, u);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) uf[((long long)(4 * a + b) * Cout + co) * Cin + ci] = u[a][b];
+    }
+    if (ud) {
+        float kr[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) kr[i][j] = k[2 - i][2 - j];
+        g_transform(kr, u);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) ud[((long long)(4 * a + b) * Cin + ci) * Cout + co] = u[a][b];
+    }
+}
+
+__global__ void wino_pack_kernel(const float* w, float* uf, float* ud, int Cout, int Cin) {
+    wino_pack_one(w, uf, ud, Cout, Cin, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// all 3x3 kernels of a network in one launch; items: 8 x int64 per tensor {w, uf, ud, Cout, Cin, -, -, first block}
+__global__ void wino_pack_batched_kernel(const long long* items, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[8 * mid + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* it = items + 8 * lo;
+    wino_pack_one(reinterpret_cast<const float*>(it[0]), reinterpret_cast<float*>(it[1]), reinterpret_cast<float*>(it[2]), (int)it[3],
+                  (int)it[4], ((long long)blockIdx.x - it[7]) * blockDim.x + threadIdx.x);
+}
+
+unsigned long long* g_probe = nullptr;
+
+inline int ilog2(int v) { return 31 - __builtin_clz((unsigned)v); }
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+struct Plan { bool ok; int TW, TH, TPI, P, RIN, NTR, NS, nwgimg; };
+
+Plan plan_of(int H, int W) {
+    Plan g = {};
+    if (H % 2 || W % 2) return g;
+    g.TW = W / 2; g.TH = H / 2; g.TPI = g.TW * g.TH;
+    if (!pow2(g.TW) || !pow2(g.TH) || g.TW < 4 || g.TW > 64 || g.TPI < 16) return g;
+    if (g.TPI >= TILES_WG) { g.nwgimg = 1; g.NTR = TILES_WG / g.TW; if (g.NTR < 1 || g.NTR > g.TH) return g; }
+    else { g.nwgimg = TILES_WG / g.TPI; g.NTR = g.TH; }
+    g.RIN = 2 * g.NTR + 2;
+    g.P = g.TW >= 16 ? g.TW + 1 : (g.TW == 8 ? 10 : 5);       // pitch chosen so 16 consecutive tiles read 16 distinct bank quads
+    const int slots = g.nwgimg * g.RIN * 2 * g.P;
+    g.NS = (slots + 127) / 128 * 128;
+    g.ok = g.NS <= 640;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int vd_conv3x3_wino_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t ldy,
+                                         int64_t ldres) {
+    const Plan g = plan_of(H, W);
+    if (!g.ok || Cin % KT || Cout % 4 || nimg <= 0) return 0;
+    const long long px = (long long)nimg * H * W;
+    const long long lim = 0x7FFFFFF0LL / 4;
+    if (px * ldx >= lim || px * ldy >= lim || (ldres > 0 && px * ldres >= lim) || 16LL * Cout * Cin >= lim) return 0;
+    if (ldx % 4 || ldy % 4 || ldres % 4) return 0;
+    return 1;
+}
+
+extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, const float* bias, const float* res, int64_t ldres,
+                               float* y, int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                               float* stats_part, void* stream) {
+    VD_REQUIRE(xin && U && y, "vd_conv3x3_wino: null operand");
+    VD_REQUIRE(vd_conv3x3_wino_supported(nimg, H, W, Cin, Cout, ldx, ldy, res ? ldres : 0),
+               "vd_conv3x3_wino: unsupported geometry nimg=%d H=%d W=%d Cin=%d Cout=%d (use vd_conv3x3)", nimg, H, W, Cin, Cout);
+    VD_REQUIRE(vd_aligned16(xin) && vd_aligned16(U) && vd_aligned16(y) && (!res || vd_aligned16(res)) && (!bias || vd_aligned16(bias)),
+               "vd_conv3x3_wino: operands must be 16-byte aligned");
+    const Plan g = plan_of(H, W);
+    WinoArgs a = {};
+    a.x = xin; a.ldx = ldx; a.U = U; a.bias = bias; a.res = res; a.ldr = ldres; a.y = y; a.ldy = ldy; a.stats = stats_part;
+    a.nimg = nimg; a.H = H; a.W = W; a.K = Cin; a.Cout = Cout;
+    a.TW = g.TW; a.TH = g.TH; a.TPI = g.TPI; a.P = g.P; a.RIN = g.RIN; a.NTR = g.NTR; a.NIW = g.nwgimg;
+    a.lgTW = ilog2(g.TW); a.lgTPI = ilog2(g.TPI); a.ntiles = nimg * g.TPI;
+    a.invP2 = 1.0f / (float)(2 * g.P); a.invRIN = 1.0f / (float)g.RIN;
+    const dim3 grid((Cout + TN - 1) / TN, (a.ntiles + TILES_WG - 1) / TILES_WG);
+    VD_REQUIRE(grid.y <= 65535, "vd_conv3x3_wino: too many tile groups (%u)", grid.y);
+    hipStream_t st = (hipStream_t)stream;
+    a.probe = g_probe;
+    if (g_probe && g.NS <= 384) {          // timing probe (tests/probe/wino_phases.py): per-wave phase stamps
+        if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<384, true, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((wino_conv_kernel<384, false, true>), grid, dim3(512), 0, st, a);
+        VD_LAUNCH_CHECK("wino_conv_kernel(probe)");
+        return 0;
+    }
+#define VD_WINO_LAUNCH(NSV)                                                                                             \
+    do {                                                                                                                \
+        if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<NSV, true>), grid, dim3(512), 0, st, a);                   \
+        else hipLaunchKernelGGL((wino_conv_kernel<NSV, false>), grid, dim3(512), 0, st, a);                             \
+    } while (0)
+    if (g.NS <= 384) VD_WINO_LAUNCH(384);
+    else if (g.NS <= 512) VD_WINO_LAUNCH(512);
+    else VD_WINO_LAUNCH(640);
+#undef VD_WINO_LAUNCH
+    VD_LAUNCH_CHECK("wino_conv_kernel");
+    vd_g_last_tile = ((16 * 1000) + 128) * 1000 + TN;          // (chunk of the statistics = 64 pixels = BM / 2 with BM = 128)
+    return 0;
+}
+
+/* timing probe only: device buffer of 64 u64 per workgroup (8 per wave: start, loop start, loop end, end, cycles at the tile
+ * barrier, first-tile cycles, K tiles, realtime), or NULL to switch the probe off */
+extern "C" int vd_wino_set_probe(unsigned long long* buf) { g_probe = buf; return 0; }
+
+extern "C" int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf, float* ud, void* stream) {
+    VD_REQUIRE(w_oihw && (uf || ud), "vd_wino_pack: null pointer");
+    const long long tot = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, uf, ud, Cout, Cin);
+    VD_LAUNCH_CHECK("wino_pack_kernel");
+    return 0;
+}
+
+extern "C" int vd_wino_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream) {
+    VD_REQUIRE(items_dev && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "vd_wino_pack_batched: bad table");
+    hipLaunchKernelGGL(wino_pack_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(items_dev), n);
+    VD_LAUNCH_CHECK("wino_pack_batched_kernel");
+    return 0;
+}

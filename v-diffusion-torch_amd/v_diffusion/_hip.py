@@ -38,6 +38,11 @@ _SIGNATURES = {
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_last_tile": (C.c_int, []),
     "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vd_conv3x3_wino_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64]),
+    "vd_conv3x3_wino": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vd_wino_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "vd_wino_set_probe": (C.c_int, [_vp]),
+    "vd_wino_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
@@ -154,6 +159,15 @@ class _Timed:
             PROFILE.append((name, self.flops, self.e0, self.e1))
 
 
+class _TimedName(_Timed):
+    """PROFILE record under a fixed kernel name (launches whose instantiation does not come from vd_gemm_last_tile)"""
+
+    def __exit__(self, *exc):
+        if PROFILE is not None and exc[0] is None:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+
+
 def workspace(nbytes, device, tag="default"):
     """Per-(device, stream, tag) scratch buffer, grown on demand.  Kernels on one stream are ordered, so a scratch
     region can be reused by the next launch on the same stream."""
@@ -209,6 +223,30 @@ def gn_coef_from_partials(parts, nimg, HW, gamma, beta, film, coef, G=32, eps=1e
     (p1, c1, k1), (p2, c2, k2) = parts[0], (parts[1] if len(parts) > 1 else (None, 0, 0))
     _check(lib().vd_gn_coef_from_partials(ptr(p1), c1, k1, ptr(p2), c2, k2, nimg, HW, G, eps, ptr(gamma), ptr(beta), ptr(film),
                                           ptr(coef), stream()), "vd_gn_coef_from_partials")
+
+
+WINO = os.environ.get("VD_WINO", "1") != "0"      # A/B switch: 0 sends every 3x3 convolution to the direct implicit GEMM
+
+
+def wino_supported(nimg, H, W, Cin, Cout, ldx, ldy, ldres=0):
+    return WINO and bool(lib().vd_conv3x3_wino_supported(nimg, H, W, Cin, Cout, ldx, ldy, ldres))
+
+
+def wino_pack(w, Cout, Cin, uf=None, ud=None):
+    _check(lib().vd_wino_pack(ptr(w), Cout, Cin, ptr(uf), ptr(ud), stream()), "vd_wino_pack")
+
+
+def wino_pack_batched(table, n, total_blocks):
+    assert table.is_cuda and table.dtype == torch.int64 and table.is_contiguous()
+    _check(lib().vd_wino_pack_batched(table.data_ptr(), n, total_blocks, stream()), "vd_wino_pack_batched")
+
+
+def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, stats_part=None):
+    """Winograd F(2x2,3x3) form (see vd_conv3x3_wino); `flops` recorded = the direct convolution's (algorithmic) count, of
+    which the matrix cores execute 4/9"""
+    with _TimedName("wino_conv_kernel<" + ("stats" if stats_part is not None else "plain") + ">", 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3_wino(ptr(x), ldx, ptr(U), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
+                                     ptr(stats_part), stream()), "vd_conv3x3_wino")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):

@@ -196,8 +196,41 @@ class UNetEngine:
                 blk += (n + 255) // 256
             table = torch.tensor(rows, dtype=torch.int64).to(dev)
             st = self._pack_state[bool(need_d)] = dict(key=key, wf=wf_all, wd=wd_all, table=table, n=len(ws), blocks=blk, views=views)
+            if H.WINO:
+                # Winograd-domain kernels U = G w G^T (csrc/wino.hip): [16][Cout][Cin] forward, [16][Cin][Cout] input gradient
+                old = st.get("uf")
+                uf_all = old if (old is not None and old.numel() == 16 * sum(sizes) // 9) else torch.empty(16 * sum(sizes) // 9, dtype=torch.float32, device=dev)
+                ud_all = torch.empty_like(uf_all) if need_d else None
+                wrows, wviews, woff, wblk = [], {}, 0, 0
+                for w, n in zip(ws, sizes):
+                    co, ci = w.shape[0], w.shape[1]
+                    m = 16 * co * ci
+                    uf = uf_all[woff: woff + m].view(16, co, ci)
+                    ud = ud_all[woff: woff + m].view(16, ci, co) if need_d else None
+                    wrows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr() if need_d else 0, co, ci, 0, 0, wblk])
+                    wviews[id(w)] = (uf, ud)
+                    woff += m
+                    wblk += (co * ci + 255) // 256
+                st.update(uf=uf_all, ud=ud_all, wtable=torch.tensor(wrows, dtype=torch.int64).to(dev), wblocks=wblk, wviews=wviews)
         H.pack_conv3x3_batched(st["table"], st["n"], st["blocks"])
+        if H.WINO:
+            H.wino_pack_batched(st["wtable"], st["n"], st["wblocks"])
+            self._wino = st["wviews"]
+        else:
+            self._wino = None
         return st["views"]
+
+    def _conv(self, x, ldx, w, bias, y, ldy, B, Hh, Ww, Cin, Cout, dgrad=False, res=None, ldres=0, stats_part=None):
+        """3x3 convolution with kernel ``w`` (forward) or its input gradient (``dgrad``: x = dy, Cin/Cout are the GEMM's):
+        Winograd F(2x2,3x3) wherever the geometry is served, the direct implicit GEMM otherwise."""
+        wino = getattr(self, "_wino", None)
+        if wino is not None and id(w) in wino and H.wino_supported(B, Hh, Ww, Cin, Cout, ldx, ldy, ldres if res is not None else 0):
+            U = wino[id(w)][1 if dgrad else 0]
+            if U is not None:
+                H.conv3x3_wino(x, ldx, U, bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres, stats_part=stats_part)
+                return
+        H.conv3x3(x, ldx, self._pack_d(w) if dgrad else self._pack_f(w), bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres,
+                  stats_part=stats_part)
 
     def _pack_f(self, w, cin_p=None):
         if self._packed is not None and id(w) in self._packed:
@@ -355,7 +388,7 @@ class UNetEngine:
         coef1 = self._norm(x, x_parts, mod.norm1, None, 1, 0.0, 0, rs, a1, B, Hh, Ww, Cin)
         h1 = self._new(x, B, Ho, Wo, Cout)
         ph = self._part(x, B, Ho * Wo, Cout)
-        H.conv3x3(a1, Cin, self._pack_f(mod.conv1.weight), mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout, stats_part=ph)
+        self._conv(a1, Cin, mod.conv1.weight, mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout, stats_part=ph)
         h1_parts = self._parts(ph, Cout, Ho * Wo)
         c2, fi = self.film_slot[prefix]
         film = films[c2][fi]                              # [B][2*Cout], contiguous slice of the group's batched GEMM output
@@ -374,8 +407,8 @@ class UNetEngine:
         else:
             sk = xs
         pd = self._part(x, B, Ho * Wo, Cout)
-        H.conv3x3(a2, Cout, self._pack_f(mod.conv2.weight), mod.conv2.bias, dest, _ld(dest), B, Ho, Wo, Cout, Cout, res=sk,
-                  ldres=_ld(sk), stats_part=pd)
+        self._conv(a2, Cout, mod.conv2.weight, mod.conv2.bias, dest, _ld(dest), B, Ho, Wo, Cout, Cout, res=sk,
+                   ldres=_ld(sk), stats_part=pd)
         out_parts = self._parts(pd, Cout, Ho * Wo)
         if tape is not None:
             tape[prefix] = dict(x=x, coef1=coef1, a1=a1, h1=h1, coef2=coef2, a2=a2, film=film, xs=xs if has_skip else None,
@@ -391,7 +424,7 @@ class UNetEngine:
         H.conv3x3_wgrad(a2, Cout, dy, lddy, B, Ho, Wo, Cout, Cout, G[prefix + ".conv2.weight"], Cout, Cout,
                         dbias=G[prefix + ".conv2.bias"])
         da2 = self._new(x, B, Ho, Wo, Cout)
-        H.conv3x3(dy, lddy, self._pack_d(mod.conv2.weight), None, da2, Cout, B, Ho, Wo, Cout, Cout)
+        self._conv(dy, lddy, mod.conv2.weight, None, da2, Cout, B, Ho, Wo, Cout, Cout, dgrad=True)
         # norm2 + FiLM + SiLU + dropout
         dh1 = self._new(x, B, Ho, Wo, Cout)
         c2, fi = self.film_slot[prefix]
@@ -404,7 +437,7 @@ class UNetEngine:
         H.conv3x3_wgrad(a1, Cin, dh1, Cout, B, Ho, Wo, Cin, Cout, G[prefix + ".conv1.weight"], Cin, Cout,
                         dbias=G[prefix + ".conv1.bias"])
         da1 = self._new(x, B, Ho, Wo, Cin)
-        H.conv3x3(dh1, Cout, self._pack_d(mod.conv1.weight), None, da1, Cin, B, Ho, Wo, Cout, Cin)
+        self._conv(dh1, Cout, mod.conv1.weight, None, da1, Cin, B, Ho, Wo, Cout, Cin, dgrad=True)
         del dh1
         # skip path
         if Cin != Cout:
