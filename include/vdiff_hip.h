@@ -92,6 +92,14 @@ int vd_conv3x3_wino_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, i
 int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, const float* bias, const float* res, int64_t ldres,
                     float* y, int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                     float* stats_part, void* stream);
+/* weight gradient of the same convolution in the Winograd domain (dU = sum over tiles of (A dY A^T) (.) (B^T d B), dw = G^T dU G):
+ * same arguments and result as vd_conv3x3_wgrad (dw in OIHW, optional dbias), 2.25x fewer MFMA cycles; deterministic (split-K
+ * slab planes summed in a fixed order).  Geometry as vd_conv3x3_wino_supported but Cin, Cout only need to be multiples of 4. */
+int vd_conv3x3_wgrad_wino_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t lddy);
+size_t vd_conv3x3_wgrad_wino_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int vd_conv3x3_wgrad_wino(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                          int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                          int32_t accumulate, float* ws, size_t ws_bytes, void* stream);
 /* diagnostics: per-wave phase timestamps of the next vd_conv3x3_wino launches into buf (32 x uint64 per workgroup), NULL = off */
 int vd_wino_set_probe(unsigned long long* buf);
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);

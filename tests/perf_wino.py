@@ -46,3 +46,27 @@ for nimg, Hh, Ww, Cin, Cout in SHAPES:
     H.conv3x3_wino(x, Cin, uf, b, y2, Cout, nimg, Hh, Ww, Cin, Cout, res=res, ldres=Cout)
     err = (y - y2).abs().max().item()
     print(f"{nimg}x{Hh}x{Ww} {Cin}->{Cout}: " + " | ".join(out) + f" | max|direct-wino| {err:.2e}", flush=True)
+
+print("---- weight gradient")
+for nimg, Hh, Ww, Cin, Cout in SHAPES:
+    x = torch.randn(nimg, Hh, Ww, Cin, device=DEV)
+    dy = torch.randn(nimg, Hh, Ww, Cout, device=DEV)
+    dw, dw2 = torch.empty(Cout, Cin, 3, 3, device=DEV), torch.empty(Cout, Cin, 3, 3, device=DEV)
+    db = torch.empty(Cout, device=DEV)
+    fl = 2.0 * nimg * Hh * Ww * Cout * 9 * Cin
+    out = []
+    for name, fn in (("direct", lambda: H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db, direct=True)),
+                     ("wino", lambda: H.conv3x3_wgrad_wino(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=db))):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out.append(f"{name} {ms:.3f} ms {fl / ms / 1e9:.1f} TF")
+    rel = ((dw - dw2).norm() / dw.norm()).item()
+    print(f"{nimg}x{Hh}x{Ww} {Cin}->{Cout}: " + " | ".join(out) + f" | rel-L2 direct vs wino {rel:.2e}", flush=True)

@@ -7,7 +7,9 @@ asserts (vd_gemm_last_tile) that the instantiation named in DESIGN section 1 rea
                                        gemm_dma_kernel<128,128,IM2COL,ROW,false,32,false>   the same for the 16x16 layers (512 workgroups)
   test_conv3x3_dgrad_at_bench_shape    gemm_dma_kernel<128,128,IM2COL,ROW,false,16,true>    forward / input gradient (TR epilogue)
   test_conv3x3_wgrad_at_bench_shapes   gemm_dma_kernel<128,128,COL,IM2COL,true,16,true>     weight gradient, 131072 / 32768 pixels
-  test_cifar_train_step_b64_vs_oracle  everything above inside one full CIFAR-cond train step at B = 64 vs the CPU oracle
+  test_cifar_train_step_b64_vs_oracle  one full CIFAR-cond train step at B = 64 vs the CPU oracle: wino_conv_kernel for the 108
+                                       residual-block convolutions + the weight-gradient form above; ..._direct_convolutions re-runs
+                                       it with VD_WINO=0 (the direct forms above inside the full step)
 
 Truth = fp64: F.conv2d on the CPU for a subset of images (exact, slow) and fp64 matmuls on the GPU for whole tensors (the
 GPU-side checker is itself validated against the CPU one inside the test).  Reference ops: modules.py:141-144 (conv),
@@ -174,16 +176,25 @@ def test_cifar_train_step_b64_vs_oracle():
         r = real_wgrad(*a, **k)
         seen.add(("wgrad", orig()))
         return r
-    real_conv, real_wgrad = _hip.conv3x3, _hip.conv3x3_wgrad
-    _hip.conv3x3, _hip.conv3x3_wgrad = spy_conv, spy_wgrad
+    wino_calls = [0]
+
+    def spy_wino(*a, **k):
+        wino_calls[0] += 1
+        return real_wino(*a, **k)
+    real_conv, real_wgrad, real_wino = _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino
+    _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino = spy_conv, spy_wgrad, spy_wino
     try:
         loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
         loss.mean().backward()
         torch.cuda.synchronize()
     finally:
-        _hip.conv3x3, _hip.conv3x3_wgrad = real_conv, real_wgrad
+        _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino = real_conv, real_wgrad, real_wino
     code = lambda tr, kt: ((tr * 100 + kt) * 1000 + 128) * 1000 + 128
-    assert ("conv", code(0, 16)) in seen and ("conv", code(1, 16)) in seen and ("wgrad", code(1, 16)) in seen, sorted(seen)
+    assert ("wgrad", code(1, 16)) in seen, sorted(seen)
+    if _hip.WINO:           # every residual-block convolution of this network is served by the Winograd kernel
+        assert wino_calls[0] == 108 and not any(k == "conv" for k, _ in seen), (wino_calls, sorted(seen))
+    else:                   # VD_WINO=0 (test_cifar_train_step_b64_direct_convolutions): the direct implicit-GEMM forms
+        assert ("conv", code(0, 16)) in seen and ("conv", code(1, 16)) in seen and wino_calls[0] == 0, sorted(seen)
     # ---- CPU oracle, same weights / inputs
     torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
     sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -199,3 +210,17 @@ def test_cifar_train_step_b64_vs_oracle():
         worst = max(worst, err / max(ref.norm().item(), 1e-2 * gmax))
         assert err <= 1e-4 * ref.norm().item() + 1e-6 * gmax, f"{k}: rel-L2 {err / max(ref.norm().item(), 1e-30):.3e}"
     print(f"B=64 train step vs oracle: worst per-tensor gradient rel-L2 {worst:.2e}")
+
+
+def test_cifar_train_step_b64_direct_convolutions():
+    """the same step with the Winograd path switched off (VD_WINO=0, read once per process): the KT = 16 direct
+    implicit-GEMM instantiations inside the full step, against the same oracle"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "--no-header", "-p", "no:cacheprovider",
+                        "-k", "test_cifar_train_step_b64_vs_oracle"], env=dict(os.environ, VD_WINO="0"), capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -187,7 +187,7 @@ def test_conv3x3_wgrad(H, case):
     F.conv2d(x[:, :Cin_w], w32, padding=1).backward(dy[:, :Cout_w])
     dw = torch.ones(Cout_w, Cin_w, 3, 3, device=DEV)
     db = torch.ones(Cout_w, device=DEV)
-    H.conv3x3_wgrad(nhwc(x), Cin, nhwc(dy), Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin_w, Cout_w, accumulate=True, dbias=db)
+    H.conv3x3_wgrad(nhwc(x), Cin, nhwc(dy), Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin_w, Cout_w, accumulate=True, dbias=db, direct=True)
     torch.cuda.synchronize()
     close(dw, w64.grad + 1.0, w32.grad + 1.0, name="conv wgrad")
     close(db, dy[:, :Cout_w].double().sum((0, 2, 3)) + 1.0, dy[:, :Cout_w].sum((0, 2, 3)) + 1.0, name="conv dbias")
@@ -749,3 +749,42 @@ def test_conv3x3_wino_rejects_unsupported(H):
     x = torch.zeros(2, 4, 4, 32, device=DEV)
     with pytest.raises(H.HipError, match="unsupported geometry"):
         H.conv3x3_wino(x, 32, torch.zeros(16, 32, 32, device=DEV), None, torch.empty_like(x), 32, 2, 4, 4, 32, 32)
+
+
+WINO_WGRAD_CASES = [  # nimg, H, W, Cin, Cout, Cin_w, Cout_w, ldx_extra, lddy_extra
+    (2, 32, 32, 64, 64, 64, 64, 0, 0),        # 16 tiles per row: one stage = one tile-row segment, 2 stages per row? (TW = 16: one)
+    (3, 16, 16, 32, 96, 32, 96, 32, 64),      # 8 tiles per row (stage = 2 tile rows), ld > C, partial 64-blocks
+    (5, 8, 8, 48, 36, 48, 36, 0, 4),          # 4 tiles per row (stage = one image)
+    (1, 64, 64, 16, 32, 16, 32, 0, 0),        # 32 tiles per row: two stages per tile row (interior left / right borders)
+    (2, 16, 32, 32, 32, 32, 32, 0, 0),        # non-square
+    (4, 32, 32, 4, 32, 3, 32, 0, 0), (4, 32, 32, 32, 4, 32, 3, 0, 0),     # padded thin sides
+    (8, 32, 32, 256, 256, 256, 256, 0, 0), (8, 16, 16, 512, 256, 512, 256, 0, 0), (32, 8, 8, 256, 256, 256, 256, 0, 0),
+    (2, 64, 64, 192, 192, 192, 192, 0, 0)]
+
+
+@pytest.mark.parametrize("case", WINO_WGRAD_CASES)
+def test_conv3x3_wgrad_wino(H, case):
+    """vd_conv3x3_wgrad_wino == autograd of F.conv2d with respect to the kernel and the bias (fp64 truth, torch fp32 yardstick;
+    the Winograd form carries ~2x the rounding error of a direct fp32 sum: slack 8), bitwise reproducible, accumulate mode."""
+    nimg, Hh, Ww, Cin, Cout, Cin_w, Cout_w, ex, ey = case
+    assert H.lib().vd_conv3x3_wgrad_wino_supported(nimg, Hh, Ww, Cin, Cout, Cin + ex, Cout + ey) == 1
+    x = torch.zeros(nimg, Cin, Hh, Ww)
+    x[:, :Cin_w] = rnd(nimg, Cin_w, Hh, Ww, seed=1)
+    dy = torch.zeros(nimg, Cout, Hh, Ww)
+    dy[:, :Cout_w] = rnd(nimg, Cout_w, Hh, Ww, seed=2)
+    w64 = torch.zeros(Cout_w, Cin_w, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[:, :Cin_w].double(), w64, padding=1).backward(dy[:, :Cout_w].double())
+    w32 = torch.zeros(Cout_w, Cin_w, 3, 3, requires_grad=True)
+    F.conv2d(x[:, :Cin_w], w32, padding=1).backward(dy[:, :Cout_w])
+    dw = torch.ones(Cout_w, Cin_w, 3, 3, device=DEV)
+    db = torch.ones(Cout_w, device=DEV)
+    xd, dyd = nhwc(x, Cin + ex), nhwc(dy, Cout + ey)
+    H.conv3x3_wgrad_wino(xd, Cin + ex, dyd, Cout + ey, nimg, Hh, Ww, Cin, Cout, dw, Cin_w, Cout_w, accumulate=True, dbias=db)
+    torch.cuda.synchronize()
+    close(dw, w64.grad + 1.0, w32.grad + 1.0, slack=8.0, floor=4e-6, name="wino wgrad")
+    close(db, dy[:, :Cout_w].double().sum((0, 2, 3)) + 1.0, dy[:, :Cout_w].sum((0, 2, 3)) + 1.0, slack=8.0, floor=4e-6, name="wino dbias")
+    a, b = torch.empty_like(dw), torch.empty_like(dw)
+    H.conv3x3_wgrad_wino(xd, Cin + ex, dyd, Cout + ey, nimg, Hh, Ww, Cin, Cout, a, Cin_w, Cout_w)
+    H.conv3x3_wgrad_wino(xd, Cin + ex, dyd, Cout + ey, nimg, Hh, Ww, Cin, Cout, b, Cin_w, Cout_w)
+    assert torch.equal(a, b), "not bitwise reproducible"
+    close(a, w64.grad, w32.grad, slack=8.0, floor=4e-6, name="wino wgrad (no accumulate, no bias)")

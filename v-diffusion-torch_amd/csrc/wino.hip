@@ -514,3 +514,331 @@ extern "C" int vd_wino_pack_batched(const int64_t* items_dev, int32_t n, int64_t
     VD_LAUNCH_CHECK("wino_pack_batched_kernel");
     return 0;
 }
+
+// ==================================================================================================================
+// Weight gradient in the Winograd domain (autograd of modules.py:141-144 with respect to the kernel):
+//   dU[xi][co][ci] = sum_t dM[xi][t][co] V[xi][t][ci]        dM = A dY_t A^T (2x2 -> 4x4),  V = B^T d_t B as in the forward pass
+//   dw[co][ci]     = G^T dU[.][co][ci] G                     (4x4 -> 3x3)
+// i.e. 16 GEMMs whose K index is the tile (pixels / 4): 2.25x fewer MFMA cycles than the implicit GEMM over pixels.
+// Workgroup = 8 waves = a 64 (co) x 64 (ci) block of all 16 xi over a range of tile groups (split-K slab); wave w owns xi half
+// ah = w >> 2 (a in {2ah, 2ah+1}), co half (w >> 1) & 1 and ci half w & 1: 8 xi x (2x2 blocks of 16x16) = 128 accumulator registers.
+// One stage = 16 consecutive tiles: their 64 dY pixels and their input patch (both with all 64 channels of the block, 256 B per
+// pixel slot) go HBM -> LDS by DMA; a K step is 4 tiles (the k index of v_mfma_f32_16x16x4_f32 = lane >> 4 picks the tile), each
+// lane reads the 2 channels it feeds as MFMA rows / columns with ds_read_b64 (the two 128-byte halves of odd slots are swapped
+// so that the tiles of a lane pair fall on different banks), transforms them in registers and issues 32 MFMAs.
+// Signs: A has a row (0 -1) and G-side sums use -dU[.][3]; both are folded into the epilogue (the operands carry |coefficients|).
+// Epilogue: G^T . G in registers; each xi-half wave writes its partial 3x3 block to its own slab plane; wino_wgrad_reduce sums the
+// planes of all slabs in a fixed order into OIHW (bitwise reproducible, no atomics).
+constexpr int WG_T = 16;                    // tiles per stage
+constexpr int WG_NSX = 136;                 // patch slots per stage (4 rows x (17 odd + 17 even) is the largest geometry)
+constexpr int WG_DY_BYTES = 64 * 256, WG_X_BYTES = WG_NSX * 256, WG_STAGE_BYTES = WG_DY_BYTES + WG_X_BYTES;
+constexpr int WG_PIECES = WG_STAGE_BYTES / 1024;    // 50
+constexpr int WG_PPW = (WG_PIECES + 7) / 8;         // 7 DMA pieces per wave (the last round is partly idle)
+
+struct WgradArgs {
+    const float* x; long long ldx; const float* dy; long long lddy;
+    float* slabs;                      // [2 * S][9][Cout][Cin]
+    float* cpart;                      // [S][Cout] bias-gradient partials, or NULL
+    int nimg, H, W, Cin, Cout;
+    int TW, TH, TPI, lgTW, lgTPI;
+    int nstages, per;                  // stages in all, stages per slab
+};
+
+// TWS = tiles of a stage per tile row = min(W/2, 16); the stage then spans NR = 16 / TWS tile rows of one image
+template <int TWS, bool DBIAS>
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
+    constexpr int NR = WG_T / TWS, P = TWS + 1, P2 = 2 * P, LG = TWS == 16 ? 4 : (TWS == 8 ? 3 : 2);
+    static_assert((2 * NR + 2) * P2 <= WG_NSX, "patch image too large");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WG_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kq = lane >> 4;
+    const int ah = wave >> 2, mh = (wave >> 1) & 1, nh = wave & 1;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, z = blockIdx.z;
+    const int st_begin = z * p.per, st_end = min(st_begin + p.per, p.nstages);
+
+    // ---------------- DMA: per-lane source offsets relative to the stage (constant) and border classes
+    // piece q < 16: dY, slot = 4 q + lane / 16 = (2u+v) * 16 + t ; piece q >= 16: patch, slot = 4 (q - 16) + lane / 16.
+    // A slot is one pixel x 64 channels = 16 granules of 16 bytes; odd slots hold their two 128-byte halves swapped.
+    unsigned vo[WG_PPW];               // byte offset from the stage's descriptor base, or OOB (never valid)
+    unsigned bits[WG_PPW];             // border class of a patch pixel: 1 left pad column, 2 right pad column, 4 top pad row, 8 bottom pad row
+#pragma unroll
+    for (int j = 0; j < WG_PPW; ++j) {
+        const int q = wave + 8 * j;
+        unsigned v = OOB, bb = 0;
+        if (q < WG_PIECES) {
+            const int slot = (q < 16 ? 4 * q : 4 * (q - 16)) + (lane >> 4);
+            const int gl = (lane & 15) ^ ((slot & 1) << 3);               // logical granule (4 channels) this lane fetches
+            if (q < 16) {
+                const int uv = slot >> 4, t = slot & 15;
+                const int dty = t >> LG, dtx = t & (TWS - 1);
+                if (co0 + gl * 4 < p.Cout)
+                    v = (unsigned)((((long long)(2 * dty + (uv >> 1)) * p.W + 2 * dtx + (uv & 1)) * p.lddy + gl * 4) * 4);
+            } else {
+                const int rr = slot / P2, rem = slot - rr * P2;           // local input row (0 = one above the stage), place in the row pair
+                const int par = rem >= P ? 1 : 0, idx = rem - par * P;
+                const int xr = 2 * idx + par;                             // column, 0 = one left of the stage  (par 0: odd image columns)
+                if (rr < 2 * NR + 2 && ci0 + gl * 4 < p.Cin) {
+                    v = (unsigned)((((long long)rr * p.W + xr) * p.ldx + gl * 4) * 4);   // descriptor base = pixel (-1, -1) of the stage
+                    bb = (xr == 0 ? 1u : 0u) | (xr > 2 * TWS ? 2u : 0u) | (rr == 0 ? 4u : 0u) | (rr > 2 * NR ? 8u : 0u);
+                }
+            }
+        }
+        vo[j] = v; bits[j] = bb;
+    }
+    auto issue = [&](int st, int buf, bool live) {
+        // stage st = tiles [16 st, 16 st + 16): image, first tile row / column (uniform)
+        const int tile = st * WG_T;
+        const int img = tile >> p.lgTPI, tin = tile & (p.TPI - 1);
+        const int ty0 = tin >> p.lgTW, tx0 = tin & (p.TW - 1);
+        const unsigned sbits = (tx0 == 0 ? 1u : 0u) | (tx0 + TWS == p.TW ? 2u : 0u) | (ty0 == 0 ? 4u : 0u) | (ty0 + NR == p.TH ? 8u : 0u);
+        const long long pix = ((long long)img * p.H + 2 * ty0) * p.W + 2 * tx0;
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc(p.dy + pix * p.lddy + co0, live ? (int)OOB : 0);
+        // (the patch descriptor starts one row and one column early: it may point in front of the tensor, the lanes that would
+        //  read there are exactly the pad lanes, which are switched off)
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (pix - p.W - 1) * p.ldx + ci0, live ? (int)OOB : 0);
+        unsigned char* dst = smem + buf * WG_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < WG_PPW; ++j) {
+            const int q = wave + 8 * j;
+            if (j < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(dst + q * 1024), 16, (int)vo[j], 0, 0, 0);
+            else if (q < WG_PIECES) {
+                const unsigned v = (bits[j] & sbits) ? OOB : vo[j];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(dst + q * 1024), 16, (int)v, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---------------- LDS reads.  K step ks feeds tile t = 4 ks + kq of the stage to lane group kq.
+    // dY slot = (2u+v) * 16 + t;  patch slot of position (pr, q) of this xi half = ((2 dty + ah + pr) * 2 + (q & 1)) * P + dtx + (q >> 1).
+    // Lane part (kq, halves, channel pair) in two base registers per operand, the rest is an immediate offset.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int dbase = kq * 256 + ((mh ^ (kq & 1)) << 7) + lm * 8;
+    const int xb_even = WG_DY_BYTES + (kq + ah * P2) * 256 + ((nh ^ (kq & 1)) << 7) + lm * 8;
+    const int xb_odd = WG_DY_BYTES + (kq + ah * P2) * 256 + ((nh ^ (kq & 1) ^ 1) << 7) + lm * 8;
+
+    f32x4 acc[8][2][2];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[xi][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 bsum = {0.f, 0.f};
+    const bool do_bias = DBIAS && ah == 0 && nh == 0 && blockIdx.x == 0;
+
+    auto kstep = [&](const unsigned char* sb, const int ks) {
+        constexpr int dummy = 0; (void)dummy;
+        const int dty = (TWS == 16) ? 0 : (TWS == 8 ? (ks >> 1) : ks);
+        const int dtx0 = (TWS == 16) ? 4 * ks : (TWS == 8 ? 4 * (ks & 1) : 0);
+        f32x2 dyv[2][2], L[3][4];
+#pragma unroll
+        for (int uv = 0; uv < 4; ++uv) dyv[uv >> 1][uv & 1] = *reinterpret_cast<const f32x2*>(sb + dbase + (uv * 16 + 4 * ks) * 256);
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int C = ((2 * dty + pr) * 2 + (q & 1)) * P + dtx0 + (q >> 1);
+                L[pr][q] = *reinterpret_cast<const f32x2*>(sb + ((C & 1) ? xb_odd : xb_even) + C * 256);
+            }
+        if (do_bias) bsum += (dyv[0][0] + dyv[0][1]) + (dyv[1][0] + dyv[1][1]);
+        // A dY A^T restricted to this wave's rows a; |coefficients| only (signs: epilogue)
+        f32x2 m[2][2], tr[2][4];
+        if (ah == 0) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) { m[0][v] = dyv[0][v]; m[1][v] = dyv[0][v] + dyv[1][v]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tr[0][q] = L[0][q] - L[2][q]; tr[1][q] = L[1][q] + L[2][q]; }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) { m[0][v] = dyv[0][v] - dyv[1][v]; m[1][v] = dyv[1][v]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tr[0][q] = L[1][q] - L[0][q]; tr[1][q] = L[0][q] - L[2][q]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x2 A4[4], V[4];
+            A4[0] = m[a][0]; A4[1] = m[a][0] + m[a][1]; A4[2] = m[a][0] - m[a][1]; A4[3] = m[a][1];
+            V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[4 * a + b][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[b][mb], V[b][nb], acc[4 * a + b][mb][nb], 0, 0, 0);
+        }
+    };
+
+    if (st_begin < st_end) {
+        issue(st_begin, 0, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int st = st_begin; st < st_end; ++st) {
+            const int buf = (st - st_begin) & 1;
+            const unsigned char* sb = smem + buf * WG_STAGE_BYTES;
+            // the two waves of a SIMD issue their DMA bursts half a stage apart (see wino_conv_kernel)
+            if (ah == 0) issue(st + 1, buf ^ 1, st + 1 < st_end);
+            kstep(sb, 0);
+            kstep(sb, 1);
+            if (ah != 0) issue(st + 1, buf ^ 1, st + 1 < st_end);
+            kstep(sb, 2);
+            kstep(sb, 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue: partial G^T dU G of this wave's two rows a.   G^T = [1 .5 .5 0 ; 0 .5 -.5 0 ; 0 .5 .5 1]
+    // true dU[a][b] = sa(a) sb(b) acc with sa(3) = sb(3) = -1 (folded signs)
+    // lane (n = lm, rq = kq), register r: co = co0 + 32 mh + 2 (4 rq + r) + mb, ci = ci0 + 32 nh + 2 n + nb
+    float* plane = p.slabs + (long long)(2 * z + ah) * 9 * p.Cout * p.Cin;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 32 * mh + 2 * (4 * kq + r) + mb;
+            f32x2 w9[3][3];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float c[2][3];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const float d0 = acc[4 * a][mb][nb][r], d1 = acc[4 * a + 1][mb][nb][r], d2 = acc[4 * a + 2][mb][nb][r],
+                                d3 = -acc[4 * a + 3][mb][nb][r];
+                    const float h = 0.5f * (d1 + d2);
+                    c[a][0] = d0 + h; c[a][1] = 0.5f * (d1 - d2); c[a][2] = h + d3;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (ah == 0) { const float h = 0.5f * c[1][j]; w9[0][j][nb] = c[0][j] + h; w9[1][j][nb] = h; w9[2][j][nb] = h; }
+                    else { const float h = 0.5f * c[0][j]; w9[0][j][nb] = h; w9[1][j][nb] = -h; w9[2][j][nb] = h - c[1][j]; }
+                }
+            }
+            const int ci = ci0 + 32 * nh + 2 * lm;
+            if (co < p.Cout && ci < p.Cin) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        *reinterpret_cast<f32x2*>(plane + ((long long)(3 * i + j) * p.Cout + co) * p.Cin + ci) = w9[i][j];
+            }
+        }
+    if (DBIAS && do_bias && p.cpart) {
+        // sum over the 4 tiles of a K step (lanes with equal lm): lanes kq = 0 write channels co0 + 32 mh + 2 lm + {0, 1}
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = bsum[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            bsum[e] = v;
+        }
+        const int co = co0 + 32 * mh + 2 * lm;
+        if (kq == 0 && co < p.Cout) *reinterpret_cast<f32x2*>(p.cpart + (long long)z * p.Cout + co) = bsum;
+    }
+}
+
+// dw[co][ci][tap] (+)= sum over the 2 S planes (fixed order); dbias[co] (+)= sum over the S partial rows
+__global__ void wino_wgrad_reduce_kernel(const float* slabs, int planes, int Cout, int Cin, int Cout_w, int Cin_w, float* dw, int accumulate,
+                                         const float* cpart, int S, float* dbias) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dbias && idx < Cout_w) {
+        float c = 0.f;
+        for (int q = 0; q < S; ++q) c += cpart[(long long)q * Cout + idx];
+        dbias[idx] = accumulate ? dbias[idx] + c : c;
+    }
+    if (idx >= (long long)Cout * Cin) return;
+    const int co = idx / Cin, ci = idx % Cin;
+    if (co >= Cout_w || ci >= Cin_w) return;
+    const long long plane = 9LL * Cout * Cin;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    for (int q = 0; q < planes; ++q) {
+        const float* src = slabs + q * plane + idx;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[t] += src[(long long)t * Cout * Cin];
+    }
+    float* o = dw + ((long long)co * Cin_w + ci) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[t] = accumulate ? o[t] + s[t] : s[t];
+}
+
+struct WgPlan { bool ok; int TW, TH, TPI, TWs, NR, nstages, S, per; };
+
+static WgPlan wgrad_plan_wino(int nimg, int H, int W, int Cin, int Cout) {
+    WgPlan g = {};
+    if (H % 2 || W % 2 || Cin % 4 || Cout % 4 || nimg <= 0) return g;
+    g.TW = W / 2; g.TH = H / 2;
+    g.TPI = g.TW * g.TH;
+    if (!pow2(g.TW) || !pow2(g.TH) || g.TW < 4 || g.TPI < WG_T) return g;
+    g.TWs = g.TW < WG_T ? g.TW : WG_T;
+    g.NR = WG_T / g.TWs;
+    if (g.NR > g.TH) return g;
+    g.nstages = nimg * g.TPI / WG_T;
+    // slabs: one workgroup per CU and round (100 KB of LDS each); pick the count that fills whole rounds of 256 best, >= 4 stages each
+    const long long blocks = ((Cout + 63) / 64) * (long long)((Cin + 63) / 64);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int S = 1; S <= 64 && S <= g.nstages; ++S) {
+        if (S > 1 && g.nstages / S < 4) break;
+        const long long wgs = blocks * S, rounds = (wgs + 255) / 256;
+        double eff = (double)wgs / (double)(rounds * 256);
+        eff *= 1.0 - 0.002 * S;                        // mild preference for fewer slabs (less reduce traffic)
+        if (eff > best_eff) { best_eff = eff; best = S; }
+    }
+    g.per = (g.nstages + best - 1) / best;
+    g.S = (g.nstages + g.per - 1) / g.per;
+    g.ok = true;
+    return g;
+}
+
+extern "C" int vd_conv3x3_wgrad_wino_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t lddy) {
+    const WgPlan g = wgrad_plan_wino(nimg, H, W, Cin, Cout);
+    if (!g.ok || ldx % 4 || lddy % 4) return 0;
+    // 32-bit offsets inside one stage (a few rows of one image) must stay far below 2^31
+    const long long lim = 0x40000000LL / 4;
+    if ((long long)(2 * g.NR + 4) * (W + 2) * (ldx > lddy ? ldx : lddy) >= lim) return 0;
+    return 1;
+}
+
+extern "C" size_t vd_conv3x3_wgrad_wino_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    const WgPlan g = wgrad_plan_wino(nimg, H, W, Cin, Cout);
+    if (!g.ok) return 0;
+    return ((size_t)2 * g.S * 9 * Cout * Cin + (size_t)g.S * Cout) * sizeof(float);
+}
+
+extern "C" int vd_conv3x3_wgrad_wino(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                                     int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                                     int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
+    VD_REQUIRE(xin && dy && dw_oihw && ws, "vd_conv3x3_wgrad_wino: null operand");
+    VD_REQUIRE(vd_conv3x3_wgrad_wino_supported(nimg, H, W, Cin, Cout, ldx, lddy), "vd_conv3x3_wgrad_wino: unsupported geometry "
+               "nimg=%d H=%d W=%d Cin=%d Cout=%d (use vd_conv3x3_wgrad)", nimg, H, W, Cin, Cout);
+    VD_REQUIRE(Cin_w <= Cin && Cout_w <= Cout, "vd_conv3x3_wgrad_wino: real dims exceed padded dims");
+    VD_REQUIRE(vd_aligned16(xin) && vd_aligned16(dy), "vd_conv3x3_wgrad_wino: operands must be 16-byte aligned");
+    VD_REQUIRE(ws_bytes >= vd_conv3x3_wgrad_wino_ws_bytes(nimg, H, W, Cin, Cout), "vd_conv3x3_wgrad_wino: workspace too small");
+    const WgPlan g = wgrad_plan_wino(nimg, H, W, Cin, Cout);
+    WgradArgs a = {};
+    a.x = xin; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.slabs = ws;
+    a.cpart = dbias ? ws + (size_t)2 * g.S * 9 * Cout * Cin : nullptr;
+    a.nimg = nimg; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.TW = g.TW; a.TH = g.TH; a.TPI = g.TPI; a.lgTW = ilog2(g.TW); a.lgTPI = ilog2(g.TPI);
+    a.nstages = g.nstages; a.per = g.per;
+    const dim3 grid((Cin + 63) / 64, (Cout + 63) / 64, g.S);
+    hipStream_t st = (hipStream_t)stream;
+#define VD_WG_LAUNCH(T)                                                                          \
+    do {                                                                                         \
+        if (dbias) hipLaunchKernelGGL((wino_wgrad_kernel<T, true>), grid, dim3(512), 0, st, a);  \
+        else hipLaunchKernelGGL((wino_wgrad_kernel<T, false>), grid, dim3(512), 0, st, a);       \
+    } while (0)
+    if (g.TWs == 16) VD_WG_LAUNCH(16);
+    else if (g.TWs == 8) VD_WG_LAUNCH(8);
+    else VD_WG_LAUNCH(4);
+#undef VD_WG_LAUNCH
+    VD_LAUNCH_CHECK("wino_wgrad_kernel");
+    const long long tot = (long long)Cout * Cin;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, 2 * g.S, Cout, Cin, Cout_w, Cin_w,
+                       dw_oihw, accumulate, a.cpart, g.S, dbias);
+    VD_LAUNCH_CHECK("wino_wgrad_reduce_kernel");
+    return 0;
+}

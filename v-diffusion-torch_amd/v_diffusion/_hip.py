@@ -42,6 +42,9 @@ _SIGNATURES = {
     "vd_conv3x3_wino": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vd_wino_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "vd_wino_set_probe": (C.c_int, [_vp]),
+    "vd_conv3x3_wgrad_wino_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "vd_conv3x3_wgrad_wino_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "vd_conv3x3_wgrad_wino": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_wino_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
@@ -255,7 +258,19 @@ def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=
                                 int(accumulate), ptr(stats_part), stream()), "vd_conv3x3")
 
 
-def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):
+def conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):
+    nb = lib().vd_conv3x3_wgrad_wino_ws_bytes(nimg, H, W, Cin, Cout)
+    ws = workspace(nb, x.device, "wgrad")
+    with _TimedName("wino_wgrad_kernel (+ wino_wgrad_reduce_kernel)", 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3_wgrad_wino(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w,
+                                           int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad_wino")
+
+
+def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None, direct=False):
+    """weight (and bias) gradient of the 3x3 convolution: Winograd-domain kernel wherever the geometry is served (VD_WINO=0 or
+    direct=True: the implicit GEMM over pixels)"""
+    if WINO and not direct and lib().vd_conv3x3_wgrad_wino_supported(nimg, H, W, Cin, Cout, ldx, lddy):
+        return conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate, dbias)
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
     args = (ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w, int(accumulate), ws.data_ptr(),
