@@ -246,6 +246,8 @@ def main():
     ap.add_argument("--no-sample", action="store_true", help="skip the DDIM-50 CFG sampling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the CelebA (BASELINE configs[3]) secondary block")
+    ap.add_argument("--no-extras", action="store_true", help="skip the loss.item() / fwd+bwd-only variants (profiling runs: keeps the "
+                    "launch count at warmup + steps + 2 train steps)")
     ap.add_argument("--sample-steps", type=int, default=50)
     ap.add_argument("--config", choices=["cifar10", "celeba"], default="cifar10",
                     help="cifar10 = the headline workload (BASELINE configs[1]); celeba = configs[3] as the primary line")
@@ -275,7 +277,7 @@ def main():
         torch.cuda.synchronize()
 
     B = args.batch
-    r = run_training(wl, B, args.steps, args.warmup, device, rank, world, barrier, args.sample_steps)
+    r = run_training(wl, B, args.steps, args.warmup, device, rank, world, barrier, args.sample_steps, extras=not args.no_extras)
     model, diffusion, labels, RES = r["model"], r["diffusion"], r["labels"], r["res"]
     fwd_gflop = r["fwd_gflop"]
     hbm_peak = torch.cuda.max_memory_allocated(device)
