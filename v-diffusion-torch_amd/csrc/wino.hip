@@ -59,21 +59,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 
 __device__ __forceinline__ int b_swz(int row) { return (row >> 2) & 2; }
 
-// NS = patch slots per 16-byte channel chunk (multiple of 128); STATS = emit GroupNorm partial sums.
-// 8 waves (two per SIMD: with one, the wave's own LDS / DMA / transform instructions sit between its MFMAs -- 59 cycles per MFMA
-// instead of 32 in the first version of this kernel): wave w owns tile group w & 3 (16 tiles) and HALF of the xi range,
-// a in {2h, 2h+1} with h = w >> 2, for both channel blocks.  Splitting xi (not channels) between the two waves of a tile group
-// means neither repeats the other's input transform: each needs three of the four patch rows and half of the B^T . B work.
+// TW = tiles per image row (compile-time geometry: patch pitch, offsets), NS = patch slots per 16-byte channel chunk (multiple of
+// 128), STATS = emit GroupNorm partial sums.
+// 10 waves.  Waves 0-7 compute (two per SIMD: with one, the wave's own LDS / transform instructions sit between its MFMAs -- 59
+// cycles per MFMA instead of 32 in the first version of this kernel): wave w owns tile group w & 3 (16 tiles) and HALF of the xi
+// range, a in {2h, 2h+1} with h = w >> 2, for both channel blocks.  Splitting xi (not channels) between the two waves of a tile
+// group means neither repeats the other's input transform: each needs three of the four patch rows and half of the B^T . B work.
 // Their partial output transforms meet once, through LDS, in the epilogue.
-template <int NS, bool STATS, bool PROBE = false>
-__global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
+// Waves 8-9 are loaders: they issue every tile DMA of the workgroup (each `buffer_load ... lds` costs its wave ~100 cycles of
+// issue; spread over the compute waves that was 7 pieces = ~700 cycles per wave and K tile during which the SIMD's other wave
+// ran alone, and the matrix pipe idled ~12 % of the loop) and otherwise sleep at the tile barrier.
+constexpr int WINO_THREADS = 640;
+template <int TW, int NS, bool STATS, bool PROBE = false>
+__global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs p) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, tfirst = 0;
     if (PROBE) ts0 = __builtin_amdgcn_s_memtime();
+    constexpr int LGTW = TW == 4 ? 2 : (TW == 8 ? 3 : (TW == 16 ? 4 : (TW == 32 ? 5 : 6)));
+    constexpr int P = TW >= 16 ? TW + 1 : (TW == 8 ? 10 : 5);      // pitch: 16 consecutive tiles read 16 distinct bank quads
+    constexpr int P2 = 2 * P;
     constexpr int A_STAGE = 4 * NS * 4;                 // floats: 4 chunks x NS slots x 4 floats
     constexpr int NPA = 4 * NS / 64;                    // DMA pieces (1 KiB) of a patch stage
     constexpr int NPB = B_STAGE / 256;                  // 32 pieces of a U stage
-    constexpr int APW = NPA / 8, BPW = NPB / 8;         // pieces per wave
-    static_assert(NS % 128 == 0, "patch slots per chunk must give every wave whole DMA pieces");
+    constexpr int APL = NPA / 2, BPL = NPB / 2;         // pieces per loader wave
+    static_assert(NS % 128 == 0, "patch slots per chunk must give every loader wave whole DMA pieces");
     __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE];
     float* const sA = smem;
     float* const sB = smem + 2 * A_STAGE;
@@ -81,7 +89,8 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    const int tg = wave & 3, ah = wave >> 2;           // tile group, xi half
+    const int tg = wave & 3, ah = (wave >> 2) & 1;     // tile group, xi half (compute waves)
+    const bool loader = wave >= 8;
 
     // XCD-aware order (see gemm.hip): each XCD walks a contiguous range of (tile group, channel block) pairs, channel blocks
     // fastest, so the workgroups that share an input patch run on one L2
@@ -98,22 +107,22 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
     const int co0 = tbx * TN;
     const int tile0 = tby * TILES_WG;                               // first tile of the workgroup
     const int img0 = tile0 >> p.lgTPI;                              // first image
-    const int trow0 = (tile0 & (p.TPI - 1)) >> p.lgTW;              // first tile row inside it (0 when a workgroup spans images)
-    const int y_first = 2 * trow0 - 1;                              // input row held in local row 0 of every image of the workgroup
+    const int trow0 = (tile0 & (p.TPI - 1)) >> LGTW;                // first tile row inside it (0 when a workgroup spans images)
+    const int nkt = p.K / KT;
 
-    // ---------------- DMA source offsets (bytes, constant over the K loop; the channel advance lives in the descriptor base)
-    unsigned voA[APW], voB[BPW];
-    {
-        const int P2 = 2 * p.P;
+    if (loader) {
+        // ================================================================= loader waves
+        // DMA source offsets (bytes, constant over the K loop; the channel advance lives in the descriptor base)
+        const int lw = wave - 8;
+        const int y_first = 2 * trow0 - 1;                          // input row held in local row 0 of every image of the workgroup
+        unsigned voA[APL], voB[BPL];
 #pragma unroll
-        for (int j = 0; j < APW; ++j) {
-            const int q = wave + 8 * j;                             // piece id
+        for (int j = 0; j < APL; ++j) {
+            const int q = lw + 2 * j;                               // piece id
             const int chunk = q / (NS / 64);
             const int s = (q % (NS / 64)) * 64 + lane;              // slot inside the chunk
-            int rr = (int)((float)s * p.invP2);                     // s / P2 (s < 1024: one correction step is enough)
-            if (rr * P2 > s) --rr; else if ((rr + 1) * P2 <= s) ++rr;
-            const int rem = s - rr * P2;                            // position in the (odd, even) row pair
-            const int par = rem >= p.P ? 1 : 0, idx = rem - par * p.P;
+            const int rr = s / P2, rem = s - rr * P2;               // local row over all images of the workgroup, place in the (odd, even) pair
+            const int par = rem >= P ? 1 : 0, idx = rem - par * P;
             int il = (int)((float)rr * p.invRIN);                   // local image, row inside it
             if (il * p.RIN > rr) --il; else if ((il + 1) * p.RIN <= rr) ++il;
             const int r = rr - il * p.RIN;
@@ -125,45 +134,57 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
             voA[j] = vo;
         }
 #pragma unroll
-        for (int j = 0; j < BPW; ++j) {
-            const int q = wave + 8 * j;                             // piece = (xi, half): 16 rows x 64 B
+        for (int j = 0; j < BPL; ++j) {
+            const int q = lw + 2 * j;                               // piece = (xi, half): 16 rows x 64 B
             const int xi = q >> 1, half = q & 1;
             const int row = lane >> 2, c = (lane & 3) ^ b_swz(row);
             const int co = co0 + half * 16 + row;
             voB[j] = co < p.Cout ? (unsigned)(((long long)xi * p.Cout + co) * p.K + c * 4) * 4u : OOB;
         }
+        // past the K range the descriptor is empty: the DMA writes zeros into a stage nobody reads (branch-free issue)
+        auto issue_A = [&](int kt, int buf, bool live) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT, live ? (int)OOB : 0);
+            float* dst = sA + buf * A_STAGE;
+#pragma unroll
+            for (int j = 0; j < APL; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (lw + 2 * j) * 256), 16, (int)voA[j], 0, 0, 0);
+        };
+        auto issue_B = [&](int kt, int buf, bool live) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.U + kt * KT, live ? (int)OOB : 0);
+            float* dst = sB + buf * B_STAGE;
+#pragma unroll
+            for (int j = 0; j < BPL; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (lw + 2 * j) * 256), 16, (int)voB[j], 0, 0, 0);
+        };
+        issue_A(0, 0, true);
+        issue_B(0, 0, true);
+        issue_A(1, 1, nkt > 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __syncthreads();                    // the compute waves have read patch 0 out of sA[0]: it may be overwritten from here on
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            // (U of kt-1 in sB[buf^1] is dead since the barrier; patch kt was read out of sA[buf] during iteration kt-1 / the prologue)
+            issue_B(kt + 1, buf ^ 1, kt + 1 < nkt);
+            issue_A(kt + 2, buf, kt + 2 < nkt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        __syncthreads();                    // (the epilogue's exchange barrier)
+        return;
     }
-    // DMA of K tile kt into stage `buf`; past the K range every lane's offset is out of range (the DMA then writes zeros into a
-    // stage nobody reads), so the issue is branch-free and the loop body stays one basic block
-    auto issue_A = [&](int kt, int buf, bool live) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT, live ? (int)OOB : 0);
-        float* dst = sA + buf * A_STAGE;
-#pragma unroll
-        for (int j = 0; j < APW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (wave + 8 * j) * 256), 16, (int)voA[j], 0, 0, 0);
-    };
-    auto issue_B = [&](int kt, int buf, bool live) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.U + kt * KT, live ? (int)OOB : 0);
-        float* dst = sB + buf * B_STAGE;
-#pragma unroll
-        for (int j = 0; j < BPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (wave + 8 * j) * 256), 16, (int)voB[j], 0, 0, 0);
-    };
 
-    // ---------------- this lane's tile and its patch base slot
+    // ===================================================================== compute waves
+    // this lane's tile and its patch base slot
     const int tl = 16 * tg + li;                                    // tile inside the workgroup
     const int tile = tile0 + tl;
     const int il = tl >> p.lgTPI;                                   // local image (0 unless the workgroup spans images)
     const int tin = (tile & (p.TPI - 1));                           // tile inside its image
-    const int ty = tin >> p.lgTW, tx = tin & (p.TW - 1);
-    const int slot0 = ((il * p.RIN + 2 * (ty - trow0)) * 2) * p.P + tx;      // slot of patch position (p=0, q=0), chunk 0
+    const int ty = tin >> LGTW, tx = tin & (TW - 1);
+    const int slot0 = ((il * p.RIN + 2 * (ty - trow0)) * 2) * P + tx;        // slot of patch position (p=0, q=0), chunk 0
     // this wave's xi half needs patch rows ah .. ah+2:  a=0: p0-p2, a=1: p1+p2 | a=2: p2-p1, a=3: p1-p3
-    const float* patch_base = sA + (lq * NS + slot0 + ah * 2 * p.P) * 4;     // + chunk lq, first needed row
-    int poff[3][4];                                                 // float offsets of the 12 patch positions
-#pragma unroll
-    for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) poff[pr][q] = ((pr * 2 + (q & 1)) * p.P + (q >> 1)) * 4;
+    const float* patch_base = sA + (lq * NS + slot0 + ah * P2) * 4;          // + chunk lq, first needed row
+    auto poff = [](int pr, int q) { return ((pr * 2 + (q & 1)) * P + (q >> 1)) * 4; };    // float offset of a patch position (immediate)
 
     // the two rows of B^T this wave owns, applied over the patch row index: L[0..2] -> tr[0..1]
     auto row_transform = [&](const f32x4 (&L)[3][4], f32x4 (&tr)[2][4]) {
@@ -182,7 +203,6 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[xi][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = p.K / KT;
     // U fragment of (xi, cb): lane (n = li, kq = lq) holds U[xi][co0 + 16 cb + n][k0 + 4 kq .. +3]
     const int boff = ah * 8 * 2 * 256 + li * KT + ((lq ^ b_swz(li)) << 2);
 
@@ -190,75 +210,64 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
     // sched_group_barrier (left alone, the scheduler sinks every fragment read to just in front of its first MFMA and the wave
     // sits on lgkmcnt): step x issues the U fragments of step x + 2 and its share of the 12 patch reads of the NEXT K tile
     // (3 LDS reads per step), then its own 8 MFMAs.
-    // The two waves of a SIMD (w and w + 4) would otherwise run in lockstep: both issue their DMA burst (7 pieces, ~100 cycles of
-    // issue each) right behind the barrier and the matrix pipe idles meanwhile.  Waves 0-3 issue theirs in front of the first
-    // half of the tile, waves 4-7 between the halves, so one of the two always has MFMAs to issue (in-kernel stamps: loop
-    // 6250 -> see DESIGN cycles per K tile).
-    f32x4 ub[3][2];
-    auto half = [&](const int a, int buf, const f32x4 (&tr)[2][4], f32x4 (&Ln)[3][4]) {
+    auto compute = [&](int buf, const f32x4 (&tr)[2][4], f32x4 (&Ln)[3][4]) {
         const float* bs = sB + buf * B_STAGE + boff;
         const float* ps = patch_base + (buf ^ 1) * A_STAGE;
-        if (a == 0) {
+        f32x4 ub[3][2];
 #pragma unroll
-            for (int z = 0; z < 2; ++z)
+        for (int z = 0; z < 2; ++z)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) ub[z][cb] = *reinterpret_cast<const f32x4*>(bs + (z * 2 + cb) * 256);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        }
-        f32x4 V[4];
-        V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
+            for (int cb = 0; cb < 2; ++cb) ub[z][cb] = *reinterpret_cast<const f32x4*>(bs + (z * 2 + cb) * 256);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int xi = 4 * a + b;
-            if (xi < 6) {
+        for (int a = 0; a < 2; ++a) {
+            f32x4 V[4];
+            V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) ub[(xi + 2) % 3][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 2) * 2 + cb) * 256);
-                Ln[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4*>(ps + poff[xi >> 2][xi & 3]);         // patch reads 0..5
-            } else {
+            for (int b = 0; b < 4; ++b) {
+                const int xi = 4 * a + b;
+                if (xi < 6) {
 #pragma unroll
-                for (int z = 0; z < 3; ++z) {                                                               // patch reads 6..11
-                    const int e = 6 + (xi - 6) * 3 + z;
-                    Ln[e >> 2][e & 3] = *reinterpret_cast<const f32x4*>(ps + poff[e >> 2][e & 3]);
+                    for (int cb = 0; cb < 2; ++cb) ub[(xi + 2) % 3][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 2) * 2 + cb) * 256);
+                    Ln[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4*>(ps + poff(xi >> 2, xi & 3));         // patch reads 0..5
+                } else {
+#pragma unroll
+                    for (int z = 0; z < 3; ++z) {                                                               // patch reads 6..11
+                        const int e = 6 + (xi - 6) * 3 + z;
+                        Ln[e >> 2][e & 3] = *reinterpret_cast<const f32x4*>(ps + poff(e >> 2, e & 3));
+                    }
                 }
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][0][j], V[b][j], acc[xi][0], 0, 0, 0);
-                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][1][j], V[b][j], acc[xi][1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][0][j], V[b][j], acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][1][j], V[b][j], acc[xi][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
     };
 
-    // ---------------- main loop: the patch stream runs one K tile ahead of the U stream
+    // ---------------- main loop: the patch stream runs one K tile ahead of the U stream (see the loader waves)
     f32x4 tr[2][4];
-    issue_A(0, 0, true);
-    issue_A(1, 1, nkt > 1);
-    issue_B(0, 0, true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
         f32x4 L[3][4];
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) L[pr][q] = *reinterpret_cast<const f32x4*>(patch_base + poff[pr][q]);
-        row_transform(L, tr);
+            for (int q = 0; q < 4; ++q) L[pr][q] = *reinterpret_cast<const f32x4*>(patch_base + poff(pr, q));
+        row_transform(L, tr);            // (consumes the reads: they are complete in front of the barrier)
     }
+    __syncthreads();
     if (PROBE) ts1 = __builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        // (patch kt was read out of sA[buf] during the previous iteration / the prologue; U of kt-1 in sB[buf^1] is dead since the barrier)
         f32x4 Ln[3][4];                    // (the last iteration reads a dead patch stage into it: unused)
-        if (ah == 0) { issue_A(kt + 2, buf, kt + 2 < nkt); issue_B(kt + 1, buf ^ 1, kt + 1 < nkt); }
-        half(0, buf, tr, Ln);
-        if (ah != 0) { issue_A(kt + 2, buf, kt + 2 < nkt); issue_B(kt + 1, buf ^ 1, kt + 1 < nkt); }
-        half(1, buf, tr, Ln);
+        compute(buf, tr, Ln);
         row_transform(Ln, tr);
         unsigned long long tw = 0;
         if (PROBE) tw = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (PROBE) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; if (kt == 0) tfirst = te - ts1; }
     }
@@ -267,9 +276,9 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
     // ---------------- epilogue: y = A^T M A (+ bias + residual)      A^T = [1 1 1 0 ; 0 1 -1 -1]
     // lane (li, lq): tile `tile`, channels co0 + 16 cb + 4 lq .. +3.  Column part in registers: s[a][v] = sum_b M[a][b] A[b][v];
     // row part: Y[0][v] = s[0][v] + s[1][v] + s[2][v], Y[1][v] = s[1][v] - s[2][v] - s[3][v] -- this wave holds a in {2h, 2h+1},
-    // so it forms its partial P[u][v] of both channel blocks, hands the block it does not finish to its partner wave through
+    // so it forms its partial PT[u][v] of both channel blocks, hands the block it does not finish to its partner wave through
     // LDS (wave h finishes channel block h) and adds the partner's partial to its own.
-    f32x4 P[2][2][2];                       // [cb][u][v]
+    f32x4 PT[2][2][2];                       // [cb][u][v]
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         f32x4 s0[2], s1[2];
@@ -279,8 +288,8 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
             s0[a] = acc[4 * a][cb] + t1;
             s1[a] = t2 - acc[4 * a + 3][cb];
         }
-        if (ah == 0) { P[cb][0][0] = s0[0] + s0[1]; P[cb][0][1] = s1[0] + s1[1]; P[cb][1][0] = s0[1]; P[cb][1][1] = s1[1]; }
-        else { P[cb][0][0] = s0[0]; P[cb][0][1] = s1[0]; P[cb][1][0] = -s0[0] - s0[1]; P[cb][1][1] = -s1[0] - s1[1]; }
+        if (ah == 0) { PT[cb][0][0] = s0[0] + s0[1]; PT[cb][0][1] = s1[0] + s1[1]; PT[cb][1][0] = s0[1]; PT[cb][1][1] = s1[1]; }
+        else { PT[cb][0][0] = s0[0]; PT[cb][0][1] = s1[0]; PT[cb][1][0] = -s0[0] - s0[1]; PT[cb][1][1] = -s1[0] - s1[1]; }
     }
     {
         // exchange area (the stages are dead: the loop ended on a barrier): [wave][k = 2u+v][lane] float4
@@ -289,13 +298,13 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int v = 0; v < 2; ++v) xch[(wave * 4 + 2 * u + v) * 64 + lane] = P[give][u][v];
+            for (int v = 0; v < 2; ++v) xch[(wave * 4 + 2 * u + v) * 64 + lane] = PT[give][u][v];
         __syncthreads();
         const int partner = wave ^ 4;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int v = 0; v < 2; ++v) P[ah][u][v] += xch[(partner * 4 + 2 * u + v) * 64 + lane];
+            for (int v = 0; v < 2; ++v) PT[ah][u][v] += xch[(partner * 4 + 2 * u + v) * 64 + lane];
     }
     const bool tile_ok = tile < p.ntiles;
     const int img = tile >> p.lgTPI;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(const WinoArgs p) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            const f32x4 val = (P[ah][u][v] + b4) + r4[u][v];
+            const f32x4 val = (PT[ah][u][v] + b4) + r4[u][v];
             if (STATS) { a1 += val; a2 += val * val; }
             const unsigned voc = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldy + co) * 4) : OOB;
             const u32x4 w = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
@@ -475,20 +484,25 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
     VD_REQUIRE(grid.y <= 65535, "vd_conv3x3_wino: too many tile groups (%u)", grid.y);
     hipStream_t st = (hipStream_t)stream;
     a.probe = g_probe;
-    if (g_probe && g.NS <= 384) {          // timing probe (tests/probe/wino_phases.py): per-wave phase stamps
-        if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<384, true, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((wino_conv_kernel<384, false, true>), grid, dim3(512), 0, st, a);
-        VD_LAUNCH_CHECK("wino_conv_kernel(probe)");
-        return 0;
-    }
-#define VD_WINO_LAUNCH(NSV)                                                                                             \
-    do {                                                                                                                \
-        if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<NSV, true>), grid, dim3(512), 0, st, a);                   \
-        else hipLaunchKernelGGL((wino_conv_kernel<NSV, false>), grid, dim3(512), 0, st, a);                             \
+    const dim3 blk(WINO_THREADS);
+#define VD_WINO_LAUNCH(TWV, NSV)                                                                                                   \
+    do {                                                                                                                            \
+        if (g_probe) {      /* timing probe (tests/probe/wino_phases.py): per-wave phase stamps */                                  \
+            if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, true, true>), grid, blk, 0, st, a);                       \
+            else hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, false, true>), grid, blk, 0, st, a);                                 \
+        } else if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, true>), grid, blk, 0, st, a);                          \
+        else hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, false>), grid, blk, 0, st, a);                                           \
     } while (0)
-    if (g.NS <= 384) VD_WINO_LAUNCH(384);
-    else if (g.NS <= 512) VD_WINO_LAUNCH(512);
-    else VD_WINO_LAUNCH(640);
+    // (tiles per row, patch slots): the square images of the shipped configs take the first form of each row
+    if (g.TW == 16 && g.NS <= 384) VD_WINO_LAUNCH(16, 384);
+    else if (g.TW == 8 && g.NS <= 384) VD_WINO_LAUNCH(8, 384);
+    else if (g.TW == 4 && g.NS <= 512) VD_WINO_LAUNCH(4, 512);
+    else if (g.TW == 32 && g.NS <= 512) VD_WINO_LAUNCH(32, 512);
+    else if (g.TW == 64) VD_WINO_LAUNCH(64, 640);
+    else if (g.TW == 16) VD_WINO_LAUNCH(16, 640);
+    else if (g.TW == 8) VD_WINO_LAUNCH(8, 640);
+    else if (g.TW == 4) VD_WINO_LAUNCH(4, 640);
+    else VD_WINO_LAUNCH(32, 640);
 #undef VD_WINO_LAUNCH
     VD_LAUNCH_CHECK("wino_conv_kernel");
     vd_g_last_tile = ((16 * 1000) + 128) * 1000 + TN;          // (chunk of the statistics = 64 pixels = BM / 2 with BM = 128)
