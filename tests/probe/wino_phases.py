@@ -19,7 +19,8 @@ for nimg, Hh, Ww, Cin, Cout, stats in ((128, 32, 32, 256, 256, False), (128, 32,
     res = torch.randn_like(y)
     b = torch.randn(Cout, device=DEV)
     part = torch.empty(H.stats_part_numel(nimg, Hh * Ww, Cout), device=DEV)
-    nwg = (Cout // 32) * (nimg * Hh * Ww // 4 // 64)
+    nwg = min(256, (Cout // 32) * (nimg * Hh * Ww // 4 // 64))      # persistent workgroups: one per CU
+    nitems = (Cout // 32) * (nimg * Hh * Ww // 4 // 64)
     buf = torch.zeros(nwg * 64, dtype=torch.int64, device=DEV)
     for _ in range(3):
         H.conv3x3_wino(x, Cin, uf, b if stats else None, y, Cout, nimg, Hh, Ww, Cin, Cout, res=res if stats else None, ldres=Cout,
@@ -32,8 +33,9 @@ for nimg, Hh, Ww, Cin, Cout, stats in ((128, 32, 32, 256, 256, False), (128, 32,
     t = buf.view(nwg, 8, 8).double().cpu()
     pro, loop, epi, wait, first, nkt = (t[..., 1] - t[..., 0]), (t[..., 2] - t[..., 1]), (t[..., 3] - t[..., 2]), t[..., 4], t[..., 5], t[..., 6]
     rt = t[..., 7]
-    print(f"{nimg}x{Hh}x{Ww} {Cin}->{Cout} stats={stats}: workgroups {nwg}, K tiles {int(nkt.max())}")
-    print(f"  cycles per wave (median): prologue {pro.median():.0f}  loop {loop.median():.0f} ({loop.median() / nkt.max():.0f} per K tile)  "
-          f"epilogue {epi.median():.0f}  parked at the tile barrier {wait.median():.0f} ({100 * wait.median() / loop.median():.1f} % of the loop)  "
-          f"first tile {first.median():.0f}")
+    per = nitems / nwg
+    tot = t[..., 3] - t[..., 0]
+    print(f"{nimg}x{Hh}x{Ww} {Cin}->{Cout} stats={stats}: workgroups {nwg} x {per:.0f} items, K tiles per item {int(nkt.max())}")
+    print(f"  cycles per wave (median): whole kernel {tot.median():.0f} = {tot.median() / per:.0f} per item = {tot.median() / per / nkt.max():.0f} per K tile "
+          f"(MFMA-bound: 4096); parked at barriers {wait.median():.0f} ({100 * wait.median() / tot.median():.1f} %); prologue of the first item {pro.median():.0f}")
     print(f"  span of workgroup end times: {(rt.max() - rt.min()) / 100:.1f} us (100 MHz clock)")

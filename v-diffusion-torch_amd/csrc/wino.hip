@@ -25,6 +25,7 @@
 //   * epilogue: A^T . A in registers (24 adds per output quad), bias, residual, dwordx4 stores, optional GroupNorm partial sums
 //     of the output (16-lane butterflies) in the layout vd_gn_stats_from_partials expects (chunk = the wave's 64 pixels).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -50,6 +51,7 @@ struct WinoArgs {
     int lgTW, lgTPI;                           // log2 (all supported geometries are powers of two)
     float invP2, invRIN;                       // 1 / (2 P), 1 / RIN (prologue index arithmetic without integer division)
     int ntiles;                                // nimg * TPI
+    int ncb, ntg;                              // work items: channel blocks x tile groups
     unsigned long long* probe;                 // timing probe build only (vd_wino_set_probe): 8 x u64 per workgroup
 };
 
@@ -61,15 +63,24 @@ __device__ __forceinline__ int b_swz(int row) { return (row >> 2) & 2; }
 
 // TW = tiles per image row (compile-time geometry: patch pitch, offsets), NS = patch slots per 16-byte channel chunk (multiple of
 // 128), STATS = emit GroupNorm partial sums.
-// 10 waves.  Waves 0-7 compute (two per SIMD: with one, the wave's own LDS / transform instructions sit between its MFMAs -- 59
-// cycles per MFMA instead of 32 in the first version of this kernel): wave w owns tile group w & 3 (16 tiles) and HALF of the xi
-// range, a in {2h, 2h+1} with h = w >> 2, for both channel blocks.  Splitting xi (not channels) between the two waves of a tile
-// group means neither repeats the other's input transform: each needs three of the four patch rows and half of the B^T . B work.
-// Their partial output transforms meet once, through LDS, in the epilogue.
-// Waves 8-9 are loaders: they issue every tile DMA of the workgroup (each `buffer_load ... lds` costs its wave ~100 cycles of
-// issue; spread over the compute waves that was 7 pieces = ~700 cycles per wave and K tile during which the SIMD's other wave
-// ran alone, and the matrix pipe idled ~12 % of the loop) and otherwise sleep at the tile barrier.
-constexpr int WINO_THREADS = 640;
+//
+// Persistent workgroups of 12 waves, one per CU (113-144 KB of LDS): a workgroup walks the work items (64 tiles x 32 channels)
+// n * G + w, n = 0, 1, ...
+//   * waves 0-7 compute (two per SIMD: with one, the wave's own LDS / transform instructions sit between its MFMAs -- 59 cycles
+//     per MFMA instead of 32 in the first version of this kernel).  Wave w owns tile group w & 3 (16 tiles) and HALF of the xi
+//     range, a in {2h, 2h+1} with h = w >> 2, for both channel blocks: splitting xi (not channels) between the two waves of a tile
+//     group means neither repeats the other's input transform (three of the four patch rows, half of the B^T . B work each).
+//     Their partial output transforms meet once per item, through LDS, in the epilogue.
+//   * waves 8-11 are loaders: they issue every tile DMA (each `buffer_load ... lds` costs its wave ~100 cycles of issue: spread
+//     over the compute waves that was ~700 cycles per wave and K tile with the SIMD's other wave running alone) and run AHEAD
+//     across items: during the last K tile of an item they already fetch the first stages of the next one, so neither the DMA
+//     latency nor the offset arithmetic of an item's prologue is exposed (11 000 cycles per item before).
+// Stage protocol (pb = parity of the item's first stage): patch of K tile t in sA[(pb+t)&1], U of t in sB[(pb+t)&1].  Loader,
+// between barrier t-1 and barrier t: U(t+1), patch(t+2) [last tile: head of the next item = patch'(0), patch'(1), U'(0) with
+// pb' = (pb + nkt) & 1], wait, barrier t.  Compute, K tile t: steps 0-6 (U fragments of t, the 12 patch reads of t+1), barrier t,
+// prefetch of the first U fragments of t+1, step 7.  One more barrier per item separates the epilogue's LDS exchange (in the
+// dead U stage) and the read of patch'(0) from the loader's next overwrite.
+constexpr int WINO_THREADS = 768;
 template <int TW, int NS, bool STATS, bool PROBE = false>
 __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs p) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, tfirst = 0;
@@ -80,7 +91,6 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
     constexpr int A_STAGE = 4 * NS * 4;                 // floats: 4 chunks x NS slots x 4 floats
     constexpr int NPA = 4 * NS / 64;                    // DMA pieces (1 KiB) of a patch stage
     constexpr int NPB = B_STAGE / 256;                  // 32 pieces of a U stage
-    constexpr int APL = NPA / 2, BPL = NPB / 2;         // pieces per loader wave
     static_assert(NS % 128 == 0, "patch slots per chunk must give every loader wave whole DMA pieces");
     __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE];
     float* const sA = smem;
@@ -91,273 +101,342 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
     const int li = lane & 15, lq = lane >> 4;
     const int tg = wave & 3, ah = (wave >> 2) & 1;     // tile group, xi half (compute waves)
     const bool loader = wave >= 8;
-
-    // XCD-aware order (see gemm.hip): each XCD walks a contiguous range of (tile group, channel block) pairs, channel blocks
-    // fastest, so the workgroups that share an input patch run on one L2
-    int tbx = blockIdx.x, tby = blockIdx.y;
-    {
-        const unsigned T = gridDim.x * gridDim.y;
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (T >= 16) {
-            const unsigned q = T / 8, r = T % 8, xcd = lin % 8, slot = lin / 8;
-            const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-            tbx = t % gridDim.x; tby = t / gridDim.x;
-        }
-    }
-    const int co0 = tbx * TN;
-    const int tile0 = tby * TILES_WG;                               // first tile of the workgroup
-    const int img0 = tile0 >> p.lgTPI;                              // first image
-    const int trow0 = (tile0 & (p.TPI - 1)) >> LGTW;                // first tile row inside it (0 when a workgroup spans images)
     const int nkt = p.K / KT;
+    const int G = gridDim.x, w = blockIdx.x;
+    const int nitems = p.ncb * p.ntg;
+    // item of round n: linear id n * G + w, re-ordered inside the round so that the workgroups of one XCD (w % 8) take
+    // neighbouring items (channel blocks fastest: they share the input patch in that XCD's L2)
+    auto item_of = [&](int n, int& tbx, int& tby) -> bool {
+        int t = n * G + w;
+        if ((G & 7) == 0) t = n * G + (w & 7) * (G >> 3) + (w >> 3);
+        if (t >= nitems) {                      // ragged last round: the permuted id may overshoot while a plain one would not
+            t = n * G + w;
+            if ((G & 7) == 0) {
+                // ids [n G, nitems) in permuted order: take the w-th valid one
+                const int valid = nitems - n * G;
+                if (w >= valid) return false;
+                t = n * G + w;
+            }
+            if (t >= nitems) return false;
+        }
+        tbx = t % p.ncb; tby = t / p.ncb;
+        return true;
+    };
 
     if (loader) {
-        // ================================================================= loader waves
-        // DMA source offsets (bytes, constant over the K loop; the channel advance lives in the descriptor base)
-        const int lw = wave - 8;
-        const int y_first = 2 * trow0 - 1;                          // input row held in local row 0 of every image of the workgroup
-        unsigned voA[APL], voB[BPL];
+        // ================================================================= loader waves (4: each issues a quarter of the pieces)
+        // Piece q = LW + 4 j.  Patch pieces: chunk = q / (NS/64) (scalar offset), pixel slot group = q % (NS/64): few distinct pixels
+        // per lane.  U pieces: half = LW & 1, xi = (LW >> 1) + 2 j (scalar offset).  LW is a compile-time constant per code path so
+        // that every register index is static.
+        auto run = [&](auto LWc) {
+            constexpr int LW = decltype(LWc)::value;
+            constexpr int SG = NS / 64, APL = NPA / 4, BPL = NPB / 4;
+            unsigned pxo[SG], pxn[SG], vb0 = 0, vb0n = 0;
+            const unsigned xi_stride2 = 2u * (unsigned)p.Cout * (unsigned)p.K * 4u;
+            auto offsets = [&](int tbx, int tby, unsigned (&px)[SG], unsigned& vb) {
+                const int co0 = tbx * TN;
+                const int tile0 = tby * TILES_WG;
+                const int img0 = tile0 >> p.lgTPI;
+                const int trow0 = (tile0 & (p.TPI - 1)) >> LGTW;
+                const int y_first = 2 * trow0 - 1;                  // input row held in local row 0 of every image of the workgroup
 #pragma unroll
-        for (int j = 0; j < APL; ++j) {
-            const int q = lw + 2 * j;                               // piece id
-            const int chunk = q / (NS / 64);
-            const int s = (q % (NS / 64)) * 64 + lane;              // slot inside the chunk
-            const int rr = s / P2, rem = s - rr * P2;               // local row over all images of the workgroup, place in the (odd, even) pair
-            const int par = rem >= P ? 1 : 0, idx = rem - par * P;
-            int il = (int)((float)rr * p.invRIN);                   // local image, row inside it
-            if (il * p.RIN > rr) --il; else if ((il + 1) * p.RIN <= rr) ++il;
-            const int r = rr - il * p.RIN;
-            const int yy = y_first + r, xx = 2 * idx - 1 + par;     // par 0: odd columns x = 2 idx - 1 ; par 1: even columns x = 2 idx
-            const int img = img0 + il;
-            unsigned vo = OOB;
-            if (il < p.NIW && img < p.nimg && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-                vo = (unsigned)((((long long)img * p.H + yy) * p.W + xx) * p.ldx + chunk * 4) * 4u;
-            voA[j] = vo;
-        }
+                for (int j = 0; j < APL && j < SG; ++j) {           // (the slot groups repeat with period <= SG)
+                    const int g = (LW + 4 * j) % SG;
+                    bool seen = false;
+                    for (int jj = 0; jj < j; ++jj) seen = seen || ((LW + 4 * jj) % SG == g);
+                    if (seen) continue;
+                    const int s = g * 64 + lane;                    // slot inside a chunk
+                    const int rr = s / P2, rem = s - rr * P2;       // local row over all images of the workgroup, place in the (odd, even) pair
+                    const int par = rem >= P ? 1 : 0, idx = rem - par * P;
+                    int il = (int)((float)rr * p.invRIN);           // local image, row inside it
+                    if (il * p.RIN > rr) --il; else if ((il + 1) * p.RIN <= rr) ++il;
+                    const int r = rr - il * p.RIN;
+                    const int yy = y_first + r, xx = 2 * idx - 1 + par;   // par 0: odd columns x = 2 idx - 1 ; par 1: even columns x = 2 idx
+                    const int img = img0 + il;
+                    unsigned vo = OOB;
+                    if (il < p.NIW && img < p.nimg && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                        vo = (unsigned)((((long long)img * p.H + yy) * p.W + xx) * p.ldx) * 4u;
+                    px[g] = vo;
+                }
+                const int row = lane >> 2, c = (lane & 3) ^ b_swz(row);
+                const int co = co0 + (LW & 1) * 16 + row;
+                vb = co < p.Cout ? (unsigned)((((long long)(LW >> 1) * p.Cout + co) * p.K + c * 4) * 4) : OOB;
+            };
+            auto issue_A = [&](int kt, int buf, const unsigned (&px)[SG]) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT);
+                float* dst = sA + buf * A_STAGE;
 #pragma unroll
-        for (int j = 0; j < BPL; ++j) {
-            const int q = lw + 2 * j;                               // piece = (xi, half): 16 rows x 64 B
-            const int xi = q >> 1, half = q & 1;
-            const int row = lane >> 2, c = (lane & 3) ^ b_swz(row);
-            const int co = co0 + half * 16 + row;
-            voB[j] = co < p.Cout ? (unsigned)(((long long)xi * p.Cout + co) * p.K + c * 4) * 4u : OOB;
-        }
-        // past the K range the descriptor is empty: the DMA writes zeros into a stage nobody reads (branch-free issue)
-        auto issue_A = [&](int kt, int buf, bool live) {
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT, live ? (int)OOB : 0);
-            float* dst = sA + buf * A_STAGE;
+                for (int j = 0; j < APL; ++j) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int q = LW + 4 * j;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + q * 256), 16, (int)px[q % SG], (q / SG) * 16, 0, 0);
+                }
+            };
+            auto issue_B = [&](int kt, int buf, unsigned vb) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.U + kt * KT);
+                float* dst = sB + buf * B_STAGE;
 #pragma unroll
-            for (int j = 0; j < APL; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (lw + 2 * j) * 256), 16, (int)voA[j], 0, 0, 0);
-        };
-        auto issue_B = [&](int kt, int buf, bool live) {
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.U + kt * KT, live ? (int)OOB : 0);
-            float* dst = sB + buf * B_STAGE;
-#pragma unroll
-            for (int j = 0; j < BPL; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (lw + 2 * j) * 256), 16, (int)voB[j], 0, 0, 0);
-        };
-        issue_A(0, 0, true);
-        issue_B(0, 0, true);
-        issue_A(1, 1, nkt > 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __syncthreads();                    // the compute waves have read patch 0 out of sA[0]: it may be overwritten from here on
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int buf = kt & 1;
-            // (U of kt-1 in sB[buf^1] is dead since the barrier; patch kt was read out of sA[buf] during iteration kt-1 / the prologue)
-            issue_B(kt + 1, buf ^ 1, kt + 1 < nkt);
-            issue_A(kt + 2, buf, kt + 2 < nkt);
+                for (int j = 0; j < BPL; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (LW + 4 * j) * 256), 16, (int)vb, (int)(j * xi_stride2), 0, 0);
+            };
+            int tbx = 0, tby = 0, nbx = 0, nby = 0;
+            bool have = item_of(0, tbx, tby);
+            int pb = 0;
+            if (have) {
+                offsets(tbx, tby, pxo, vb0);
+                issue_B(0, pb, vb0);
+                issue_A(0, pb, pxo);
+                if (nkt > 1) issue_A(1, pb ^ 1, pxo);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        __syncthreads();                    // (the epilogue's exchange barrier)
+            __syncthreads();                                        // [P0] head of the first item landed
+            for (int n = 0; have; ++n) {
+                const bool next = item_of(n + 1, nbx, nby);
+                if (next) offsets(nbx, nby, pxn, vb0n);             // (the loaders have time to spare: off the critical path)
+                __syncthreads();                                    // [P2] the compute waves have read patch(0) out of sA[pb]
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const int buf = (pb + kt) & 1;
+                    if (kt + 1 < nkt) issue_B(kt + 1, buf ^ 1, vb0);
+                    if (kt + 2 < nkt) issue_A(kt + 2, buf, pxo);
+                    if (next && kt == nkt - 1) {                    // head of the next item into the stages this item has left
+                        const int pn = (pb + nkt) & 1;
+                        issue_B(0, pn, vb0n);
+                        issue_A(0, pn, pxn);
+                        if (nkt > 1) issue_A(1, pn ^ 1, pxn);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                                // [kt]
+                }
+                __syncthreads();                                    // [X] epilogue exchange
+                pb = (pb + nkt) & 1;
+                have = next;
+                if (next) {
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) pxo[g] = pxn[g];
+                    vb0 = vb0n;
+                }
+            }
+        };
+        if (wave == 8) run(std::integral_constant<int, 0>{});
+        else if (wave == 9) run(std::integral_constant<int, 1>{});
+        else if (wave == 10) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 3>{});
         return;
     }
 
     // ===================================================================== compute waves
-    // this lane's tile and its patch base slot
-    const int tl = 16 * tg + li;                                    // tile inside the workgroup
-    const int tile = tile0 + tl;
-    const int il = tl >> p.lgTPI;                                   // local image (0 unless the workgroup spans images)
-    const int tin = (tile & (p.TPI - 1));                           // tile inside its image
-    const int ty = tin >> LGTW, tx = tin & (TW - 1);
-    const int slot0 = ((il * p.RIN + 2 * (ty - trow0)) * 2) * P + tx;        // slot of patch position (p=0, q=0), chunk 0
-    // this wave's xi half needs patch rows ah .. ah+2:  a=0: p0-p2, a=1: p1+p2 | a=2: p2-p1, a=3: p1-p3
-    const float* patch_base = sA + (lq * NS + slot0 + ah * P2) * 4;          // + chunk lq, first needed row
-    auto poff = [](int pr, int q) { return ((pr * 2 + (q & 1)) * P + (q >> 1)) * 4; };    // float offset of a patch position (immediate)
-
-    // the two rows of B^T this wave owns, applied over the patch row index: L[0..2] -> tr[0..1]
-    auto row_transform = [&](const f32x4 (&L)[3][4], f32x4 (&tr)[2][4]) {
-        if (ah == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { tr[0][q] = L[0][q] - L[2][q]; tr[1][q] = L[1][q] + L[2][q]; }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { tr[0][q] = L[1][q] - L[0][q]; tr[1][q] = L[0][q] - L[2][q]; }
-        }
-    };
-
-    f32x4 acc[8][2];
-#pragma unroll
-    for (int xi = 0; xi < 8; ++xi)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) acc[xi][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    // patch rows of this xi half in the roles (r0, r1, r2) of   tr[0] = r0 - r2,  tr[1] = sgn * r1 + r2:
+    //   h = 0 (a = 0, 1): p0 - p2, p1 + p2  -> rows (0, 1, 2), sgn = +1 ;  h = 1 (a = 2, 3): p2 - p1, p1 - p3 -> rows (2, 3, 1), sgn = -1
+    const float sgn = ah ? -1.f : 1.f;
+    const int rrow0 = ah ? 2 : 0, rrow1 = ah ? 3 : 1, rrow2 = ah ? 1 : 2;
+    auto poff = [](int q) { return ((q & 1) * P + (q >> 1)) * 4; };            // float offset of column q inside a patch row (immediate)
     // U fragment of (xi, cb): lane (n = li, kq = lq) holds U[xi][co0 + 16 cb + n][k0 + 4 kq .. +3]
     const int boff = ah * 8 * 2 * 256 + li * KT + ((lq ^ b_swz(li)) << 2);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-    // One K tile = 8 xi steps of 8 MFMAs per wave.  The LDS reads are software-pipelined by hand and pinned with
-    // sched_group_barrier (left alone, the scheduler sinks every fragment read to just in front of its first MFMA and the wave
-    // sits on lgkmcnt): step x issues the U fragments of step x + 2 and its share of the 12 patch reads of the NEXT K tile
-    // (3 LDS reads per step), then its own 8 MFMAs.
-    auto compute = [&](int buf, const f32x4 (&tr)[2][4], f32x4 (&Ln)[3][4]) {
-        const float* bs = sB + buf * B_STAGE + boff;
-        const float* ps = patch_base + (buf ^ 1) * A_STAGE;
-        f32x4 ub[3][2];
+    int tbx = 0, tby = 0;
+    bool have = item_of(0, tbx, tby);
+    int pb = 0;
+    __syncthreads();                                                // [P0]
+    f32x4 ub[2][2];                                                 // U fragments: step x of a K tile uses ub[x & 1], loaded one step ahead
+    for (int n = 0; have; ++n) {
+        const int co0 = tbx * TN;
+        const int tile0 = tby * TILES_WG;                           // first tile of the item
+        const int trow0 = (tile0 & (p.TPI - 1)) >> LGTW;            // first tile row inside its image (0 when an item spans images)
+        const int tl = 16 * tg + li;                                // this lane's tile inside the item
+        const int tile = tile0 + tl;
+        const int il = tl >> p.lgTPI;                               // local image (0 unless the item spans images)
+        const int tin = (tile & (p.TPI - 1));                       // tile inside its image
+        const int ty = tin >> LGTW, tx = tin & (TW - 1);
+        const int slot0 = ((il * p.RIN + 2 * (ty - trow0)) * 2) * P + tx;    // slot of patch position (p=0, q=0), chunk 0
+        const float* pbase = sA + (lq * NS + slot0) * 4;            // + chunk lq
+        const float* pr0 = pbase + rrow0 * P2 * 4;
+        const float* pr1 = pbase + rrow1 * P2 * 4;
+        const float* pr2 = pbase + rrow2 * P2 * 4;
+
+        f32x4 acc[8][2];
 #pragma unroll
-        for (int z = 0; z < 2; ++z)
+        for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) ub[z][cb] = *reinterpret_cast<const f32x4*>(bs + (z * 2 + cb) * 256);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            for (int cb = 0; cb < 2; ++cb) acc[xi][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // patch(0) and the first U fragments (landed: the loader waited in front of the previous barrier)
+        f32x4 tr[2][4];
+        {
+            const int o = pb * A_STAGE;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f32x4 V[4];
-            V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(pr0 + o + poff(q)), r1 = *reinterpret_cast<const f32x4*>(pr1 + o + poff(q)),
+                            r2 = *reinterpret_cast<const f32x4*>(pr2 + o + poff(q));
+                tr[0][q] = r0 - r2;
+                tr[1][q] = r1 * sgn + r2;
+            }
+            if (n == 0) {
+                const float* bs = sB + pb * B_STAGE + boff;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int xi = 4 * a + b;
-                if (xi < 6) {
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) ub[(xi + 2) % 3][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 2) * 2 + cb) * 256);
-                    Ln[xi >> 2][xi & 3] = *reinterpret_cast<const f32x4*>(ps + poff(xi >> 2, xi & 3));         // patch reads 0..5
-                } else {
-#pragma unroll
-                    for (int z = 0; z < 3; ++z) {                                                               // patch reads 6..11
-                        const int e = 6 + (xi - 6) * 3 + z;
-                        Ln[e >> 2][e & 3] = *reinterpret_cast<const f32x4*>(ps + poff(e >> 2, e & 3));
-                    }
-                }
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][0][j], V[b][j], acc[xi][0], 0, 0, 0);
-                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi % 3][1][j], V[b][j], acc[xi][1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                for (int cb = 0; cb < 2; ++cb) ub[0][cb] = *reinterpret_cast<const f32x4*>(bs + cb * 256);
             }
         }
-    };
+        __syncthreads();                                            // [P2]
+        if (PROBE && n == 0) ts1 = __builtin_amdgcn_s_memtime();
 
-    // ---------------- main loop: the patch stream runs one K tile ahead of the U stream (see the loader waves)
-    f32x4 tr[2][4];
-    __syncthreads();
-    {
-        f32x4 L[3][4];
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = (pb + kt) & 1;
+            const float* bs = sB + buf * B_STAGE + boff;
+            const int on = (buf ^ 1) * A_STAGE;                     // stage of the next patch (a dead stage in the last tile: unused)
+            f32x4 trn[2][4];
 #pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
+            for (int a = 0; a < 2; ++a) {
+                f32x4 V[4];
+                V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) L[pr][q] = *reinterpret_cast<const f32x4*>(patch_base + poff(pr, q));
-        row_transform(L, tr);            // (consumes the reads: they are complete in front of the barrier)
-    }
-    __syncthreads();
-    if (PROBE) ts1 = __builtin_amdgcn_s_memtime();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        f32x4 Ln[3][4];                    // (the last iteration reads a dead patch stage into it: unused)
-        compute(buf, tr, Ln);
-        row_transform(Ln, tr);
-        unsigned long long tw = 0;
-        if (PROBE) tw = __builtin_amdgcn_s_memtime();
-        __syncthreads();
-        if (PROBE) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; if (kt == 0) tfirst = te - ts1; }
-    }
-    if (PROBE) ts2 = __builtin_amdgcn_s_memtime();
-
-    // ---------------- epilogue: y = A^T M A (+ bias + residual)      A^T = [1 1 1 0 ; 0 1 -1 -1]
-    // lane (li, lq): tile `tile`, channels co0 + 16 cb + 4 lq .. +3.  Column part in registers: s[a][v] = sum_b M[a][b] A[b][v];
-    // row part: Y[0][v] = s[0][v] + s[1][v] + s[2][v], Y[1][v] = s[1][v] - s[2][v] - s[3][v] -- this wave holds a in {2h, 2h+1},
-    // so it forms its partial PT[u][v] of both channel blocks, hands the block it does not finish to its partner wave through
-    // LDS (wave h finishes channel block h) and adds the partner's partial to its own.
-    f32x4 PT[2][2][2];                       // [cb][u][v]
+                for (int b = 0; b < 4; ++b) {
+                    const int xi = 4 * a + b;
+                    if (xi < 7) {
+                        // U fragments of step xi + 1 (one step = 8 MFMAs = 256+ cycles ahead of their use)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        f32x4 s0[2], s1[2];
+                        for (int cb = 0; cb < 2; ++cb) ub[(xi + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 1) * 2 + cb) * 256);
+                    }
+                    if (xi < 6) {
+                        // 2 of the 12 patch reads of the next K tile (roles r2, r0 first: tr[0] early)
+                        if (xi < 2) {
+                            const f32x4 r2a = *reinterpret_cast<const f32x4*>(pr2 + on + poff(2 * xi)), r2b = *reinterpret_cast<const f32x4*>(pr2 + on + poff(2 * xi + 1));
+                            trn[1][2 * xi] = r2a; trn[1][2 * xi + 1] = r2b;             // (parked: becomes sgn * r1 + r2 below)
+                        } else if (xi < 4) {
+                            const int q0 = 2 * (xi - 2);
+                            const f32x4 r0a = *reinterpret_cast<const f32x4*>(pr0 + on + poff(q0)), r0b = *reinterpret_cast<const f32x4*>(pr0 + on + poff(q0 + 1));
+                            trn[0][q0] = r0a - trn[1][q0]; trn[0][q0 + 1] = r0b - trn[1][q0 + 1];
+                        } else {
+                            const int q0 = 2 * (xi - 4);
+                            const f32x4 r1a = *reinterpret_cast<const f32x4*>(pr1 + on + poff(q0)), r1b = *reinterpret_cast<const f32x4*>(pr1 + on + poff(q0 + 1));
+                            trn[1][q0] = r1a * sgn + trn[1][q0]; trn[1][q0 + 1] = r1b * sgn + trn[1][q0 + 1];
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    } else if (xi == 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (xi == 7) {
+                        // every read of this K tile's stages is done: barrier, then the first U fragments of the next tile (or item)
+                        unsigned long long tw = 0;
+                        if (PROBE) tw = __builtin_amdgcn_s_memtime();
+                        __syncthreads();                            // [kt]
+                        if (PROBE) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; if (kt == 0 && n == 0) tfirst = te - ts1; }
+                        const float* bn = sB + (buf ^ 1) * B_STAGE + boff;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const f32x4 t1 = acc[4 * a + 1][cb] + acc[4 * a + 2][cb], t2 = acc[4 * a + 1][cb] - acc[4 * a + 2][cb];
-            s0[a] = acc[4 * a][cb] + t1;
-            s1[a] = t2 - acc[4 * a + 3][cb];
+                        for (int cb = 0; cb < 2; ++cb) ub[0][cb] = *reinterpret_cast<const f32x4*>(bn + cb * 256);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi & 1][0][j], V[b][j], acc[xi][0], 0, 0, 0);
+                        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi & 1][1][j], V[b][j], acc[xi][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tr[a][q] = trn[a][q];
         }
-        if (ah == 0) { PT[cb][0][0] = s0[0] + s0[1]; PT[cb][0][1] = s1[0] + s1[1]; PT[cb][1][0] = s0[1]; PT[cb][1][1] = s1[1]; }
-        else { PT[cb][0][0] = s0[0]; PT[cb][0][1] = s1[0]; PT[cb][1][0] = -s0[0] - s0[1]; PT[cb][1][1] = -s1[0] - s1[1]; }
-    }
-    {
-        // exchange area (the stages are dead: the loop ended on a barrier): [wave][k = 2u+v][lane] float4
-        f32x4* xch = reinterpret_cast<f32x4*>(smem);
-        const int give = ah ^ 1;            // channel block handed to the partner
+        if (PROBE) ts2 = __builtin_amdgcn_s_memtime();
+
+        // ---------------- epilogue: y = A^T M A (+ bias + residual)      A^T = [1 1 1 0 ; 0 1 -1 -1]
+        // lane (li, lq): tile `tile`, channels co0 + 16 cb + 4 lq .. +3.  Column part in registers: s[a][v] = sum_b M[a][b] A[b][v];
+        // row part: Y[0][v] = s[0][v] + s[1][v] + s[2][v], Y[1][v] = s[1][v] - s[2][v] - s[3][v] -- this wave holds a in {2h, 2h+1},
+        // so it forms its partial PT[u][v] of both channel blocks, hands the block it does not finish to its partner wave through
+        // LDS (wave h finishes channel block h) and adds the partner's partial to its own.
+        // (the tile coordinates are re-derived here behind an optimisation barrier: kept live across the K loop they cost registers
+        //  the loop does not have -- 168 per wave at three waves per SIMD)
+        int tby_e = tby, lane_e = lane;
+        asm volatile("" : "+s"(tby_e));
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 15, lq_e = lane_e >> 4;
+        const int tile_e = tby_e * TILES_WG + 16 * tg + li_e;
+        const int tin_e = tile_e & (p.TPI - 1);
+        const int ty_e = tin_e >> LGTW, tx_e = tin_e & (TW - 1);
+        const bool tile_ok = tile_e < p.ntiles;
+        const int img = tile_e >> p.lgTPI;
+        const long long pix00 = ((long long)img * p.H + 2 * ty_e) * p.W + 2 * tx_e;
+        const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
+        const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
+        const int co = co0 + 16 * ah + 4 * lq_e;
+        const bool ok = tile_ok && co < p.Cout;                     // (Cout is a multiple of 4)
+        // residual / bias first: their latency hides behind the transform and the exchange
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && ok) b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+        f32x4 r4[2][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int v = 0; v < 2; ++v) xch[(wave * 4 + 2 * u + v) * 64 + lane] = PT[give][u][v];
-        __syncthreads();
-        const int partner = wave ^ 4;
+            for (int v = 0; v < 2; ++v) {
+                const unsigned vor = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldr + co) * 4) : OOB;
+                r4[u][v] = p.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        f32x4 PT[2][2][2];                   // [cb][u][v]
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 s0[2], s1[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const f32x4 t1 = acc[4 * a + 1][cb] + acc[4 * a + 2][cb], t2 = acc[4 * a + 1][cb] - acc[4 * a + 2][cb];
+                s0[a] = acc[4 * a][cb] + t1;
+                s1[a] = t2 - acc[4 * a + 3][cb];
+            }
+            if (ah == 0) { PT[cb][0][0] = s0[0] + s0[1]; PT[cb][0][1] = s1[0] + s1[1]; PT[cb][1][0] = s0[1]; PT[cb][1][1] = s1[1]; }
+            else { PT[cb][0][0] = s0[0]; PT[cb][0][1] = s1[0]; PT[cb][1][0] = -s0[0] - s0[1]; PT[cb][1][1] = -s1[0] - s1[1]; }
+        }
+        {
+            // exchange area = the U stage of the last K tile (dead since its barrier; the next item's head went into the other three
+            // stages): [wave][k = 2u+v][lane] float4
+            f32x4* xch = reinterpret_cast<f32x4*>(sB + ((pb + nkt - 1) & 1) * B_STAGE);
+            const int give = ah ^ 1;        // channel block handed to the partner
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) xch[(wave * 4 + 2 * u + v) * 64 + lane_e] = PT[give][u][v];
+            __syncthreads();                                        // [X]
+            const int partner = wave ^ 4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) PT[ah][u][v] += xch[(partner * 4 + 2 * u + v) * 64 + lane_e];
+        }
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int v = 0; v < 2; ++v) PT[ah][u][v] += xch[(partner * 4 + 2 * u + v) * 64 + lane];
-    }
-    const bool tile_ok = tile < p.ntiles;
-    const int img = tile >> p.lgTPI;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const long long pix00 = ((long long)img * p.H + 2 * ty) * p.W + 2 * tx;
-    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
-    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
-    const int co = co0 + 16 * ah + 4 * lq;
-    const bool ok = tile_ok && co < p.Cout;                         // (Cout is a multiple of 4)
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && ok) b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-    f32x4 r4[2][2];
+            for (int v = 0; v < 2; ++v) {
+                const f32x4 val = (PT[ah][u][v] + b4) + r4[u][v];
+                if (STATS) { a1 += val; a2 += val * val; }
+                const unsigned voc = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldy + co) * 4) : OOB;
+                const u32x4 wv = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(wv, yrs, (int)voc, 0, 0);
+            }
+        if (STATS) {
+            // sum over the wave's 16 tiles (= lanes with equal lq): fixed-order butterfly, then lane li = 0 writes its 4 channels of
+            // the [2][Cout] record of the tile group's 64-pixel chunk
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+            for (int j = 0; j < 4; ++j) {
+                float v1 = a1[j], v2 = a2[j];
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const unsigned vor = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldr + co) * 4) : OOB;
-            r4[u][v] = p.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 16); v2 += __shfl_xor(v2, o, 16); }
+                a1[j] = v1; a2[j] = v2;
+            }
+            const int wtile = tby_e * TILES_WG + 16 * tg;           // the tile group's first tile: all 16 lie in one image
+            if (li_e == 0 && wtile < p.ntiles && co < p.Cout) {
+                const int wimg = wtile >> p.lgTPI, chunk = (wtile & (p.TPI - 1)) >> 4;
+                float* o = p.stats + ((long long)wimg * (p.TPI >> 4) + chunk) * 2 * p.Cout;
+                *reinterpret_cast<f32x4*>(o + co) = a1;
+                *reinterpret_cast<f32x4*>(o + p.Cout + co) = a2;
+            }
         }
-    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const f32x4 val = (PT[ah][u][v] + b4) + r4[u][v];
-            if (STATS) { a1 += val; a2 += val * val; }
-            const unsigned voc = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldy + co) * 4) : OOB;
-            const u32x4 w = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(w, yrs, (int)voc, 0, 0);
-        }
-    if (STATS) {
-        // sum over the wave's 16 tiles (= lanes with equal lq): fixed-order butterfly, then lane li = 0 writes its 4 channels of
-        // the [2][Cout] record of the wave's 64-pixel chunk
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v1 = a1[j], v2 = a2[j];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 16); v2 += __shfl_xor(v2, o, 16); }
-            a1[j] = v1; a2[j] = v2;
-        }
-        const int wtile = tile0 + 16 * tg;                          // the tile group's first tile: all 16 lie in one image
-        if (li == 0 && wtile < p.ntiles && co < p.Cout) {
-            const int wimg = wtile >> p.lgTPI, chunk = (wtile & (p.TPI - 1)) >> 4;
-            float* o = p.stats + ((long long)wimg * (p.TPI >> 4) + chunk) * 2 * p.Cout;
-            *reinterpret_cast<f32x4*>(o + co) = a1;
-            *reinterpret_cast<f32x4*>(o + p.Cout + co) = a2;
-        }
+        pb = (pb + nkt) & 1;
+        have = item_of(n + 1, tbx, tby);
     }
     if (PROBE && p.probe) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
-            unsigned long long* o = p.probe + ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+            unsigned long long* o = p.probe + ((unsigned long long)blockIdx.x * 8 + wave) * 8;
             o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = twait; o[5] = tfirst; o[6] = (unsigned long long)nkt;
             o[7] = __builtin_amdgcn_s_memrealtime();
         }
@@ -480,8 +559,18 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
     a.TW = g.TW; a.TH = g.TH; a.TPI = g.TPI; a.P = g.P; a.RIN = g.RIN; a.NTR = g.NTR; a.NIW = g.nwgimg;
     a.lgTW = ilog2(g.TW); a.lgTPI = ilog2(g.TPI); a.ntiles = nimg * g.TPI;
     a.invP2 = 1.0f / (float)(2 * g.P); a.invRIN = 1.0f / (float)g.RIN;
-    const dim3 grid((Cout + TN - 1) / TN, (a.ntiles + TILES_WG - 1) / TILES_WG);
-    VD_REQUIRE(grid.y <= 65535, "vd_conv3x3_wino: too many tile groups (%u)", grid.y);
+    a.ncb = (Cout + TN - 1) / TN; a.ntg = (a.ntiles + TILES_WG - 1) / TILES_WG;
+    const long long items = (long long)a.ncb * a.ntg;
+    VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_wino: too many work items");
+    static int ncu = 0;                       // persistent workgroups: one per CU (the LDS footprint admits no second one)
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu = prop.multiProcessorCount;
+        else ncu = 256;
+    }
+    const dim3 grid((unsigned)(items < ncu ? items : ncu));
     hipStream_t st = (hipStream_t)stream;
     a.probe = g_probe;
     const dim3 blk(WINO_THREADS);
