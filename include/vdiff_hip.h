@@ -103,7 +103,8 @@ int vd_conv3x3_wgrad_wino(const float* xin, int64_t ldx, const float* dy, int64_
 /* diagnostics: per-wave phase timestamps of the next vd_conv3x3_wino launches into buf (32 x uint64 per workgroup), NULL = off */
 int vd_wino_set_probe(unsigned long long* buf);
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
-/* all 3x3 kernels of a network in one launch: items_dev = [n][8] int64 {w, uf, ud, Cout, Cin, 0, 0, first 256-thread block} */
+/* all 3x3 kernels of a network in one launch: items_dev = [n][8] int64 {w, uf, ud, Cout, Cin, tiled, 0, first 256-thread block};
+ * tiled = 1 (Cout, Cin multiples of 16): the tensor takes (Cout/16)*(Cin/16) blocks of one 16x16 tile, else ceil(Cout*Cin/256) */
 int vd_wino_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
 
 /* "thin" 3x3 convolutions (3-4 channels on one side: in_conv unet.py:217, out_conv :232).  The taps are moved to the thin

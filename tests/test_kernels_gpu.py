@@ -266,10 +266,10 @@ def test_conv3x3_wgrad_phases_equal_the_single_call(H):
     x, dy = nhwc(rnd(nimg, Cin, Hh, Ww, seed=1)), nhwc(rnd(nimg, Cout, Hh, Ww, seed=2))
     dw1, db1 = torch.zeros(Cout, Cin, 3, 3, device=DEV), torch.zeros(Cout, device=DEV)
     dw2, db2 = torch.ones(Cout, Cin, 3, 3, device=DEV), torch.ones(Cout, device=DEV)
-    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw1, Cin, Cout, dbias=db1)
+    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw1, Cin, Cout, dbias=db1, direct=True)
     H.PROFILE = []
     try:
-        H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=db2)
+        H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=db2, direct=True)
         names = [r[0] for r in H.PROFILE]
     finally:
         H.PROFILE = None

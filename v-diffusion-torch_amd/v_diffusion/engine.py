@@ -207,17 +207,20 @@ class UNetEngine:
                     m = 16 * co * ci
                     uf = uf_all[woff: woff + m].view(16, co, ci)
                     ud = ud_all[woff: woff + m].view(16, ci, co) if need_d else None
-                    wrows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr() if need_d else 0, co, ci, 0, 0, wblk])
+                    tiled = int(co % 16 == 0 and ci % 16 == 0)
+                    wrows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr() if need_d else 0, co, ci, tiled, 0, wblk])
                     wviews[id(w)] = (uf, ud)
                     woff += m
-                    wblk += (co * ci + 255) // 256
+                    wblk += (co // 16) * (ci // 16) if tiled else (co * ci + 255) // 256
                 st.update(uf=uf_all, ud=ud_all, wtable=torch.tensor(wrows, dtype=torch.int64).to(dev), wblocks=wblk, wviews=wviews)
-        H.pack_conv3x3_batched(st["table"], st["n"], st["blocks"])
         if H.WINO:
+            # every convolution the Winograd kernels serve needs only U; the direct packs are made per tensor, on demand, by
+            # _pack_f / _pack_d for the geometries that fall back (none in the shipped configs)
             H.wino_pack_batched(st["wtable"], st["n"], st["wblocks"])
             self._wino = st["wviews"]
-        else:
-            self._wino = None
+            return {}
+        H.pack_conv3x3_batched(st["table"], st["n"], st["blocks"])
+        self._wino = None
         return st["views"]
 
     def _conv(self, x, ldx, w, bias, y, ldy, B, Hh, Ww, Cin, Cout, dgrad=False, res=None, ldres=0, stats_part=None):
