@@ -100,7 +100,15 @@ size_t vd_conv3x3_wgrad_wino_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_
 int vd_conv3x3_wgrad_wino(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
                           int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
                           int32_t accumulate, float* ws, size_t ws_bytes, void* stream);
-/* diagnostics: per-wave phase timestamps of the next vd_conv3x3_wino launches into buf (32 x uint64 per workgroup), NULL = off */
+/* the two kernels of vd_conv3x3_wgrad_wino as separate calls (per-kernel timing, bench.py): phase 1 = slab planes (wino_wgrad_kernel),
+ * phase 2 = their fixed-order reduction into OIHW (wino_wgrad_reduce_kernel) */
+int vd_conv3x3_wgrad_wino_phase(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                                int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                                int32_t accumulate, float* ws, size_t ws_bytes, int32_t phase, void* stream);
+/* (TW * 1000 + NS) * 2 + stats of the calling thread's last vd_conv3x3_wino launch: names the instantiation
+ * wino_conv_kernel<TW, NS, stats, false> (profiling aid, like vd_gemm_last_tile) */
+int vd_wino_last_kernel(void);
+/* diagnostics: per-wave phase timestamps of the next vd_conv3x3_wino launches into buf (64 x uint64 per workgroup), NULL = off */
 int vd_wino_set_probe(unsigned long long* buf);
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
 /* all 3x3 kernels of a network in one launch: items_dev = [n][8] int64 {w, uf, ud, Cout, Cin, tiled, 0, first 256-thread block};

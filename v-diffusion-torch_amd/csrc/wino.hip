@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void wino_pack_batched_kernel(const long long*
 }
 
 unsigned long long* g_probe = nullptr;
+thread_local int g_last_wino = 0;       // (TW * 1000 + NS) * 2 + stats of the calling thread's last vd_conv3x3_wino launch
 
 inline int ilog2(int v) { return 31 - __builtin_clz((unsigned)v); }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -625,6 +626,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
     const dim3 blk(WINO_THREADS);
 #define VD_WINO_LAUNCH(TWV, NSV)                                                                                                   \
     do {                                                                                                                            \
+        g_last_wino = ((TWV) * 1000 + (NSV)) * 2 + (stats_part ? 1 : 0);                                                            \
         if (g_probe) {      /* timing probe (tests/probe/wino_phases.py): per-wave phase stamps */                                  \
             if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, true, true>), grid, blk, 0, st, a);                       \
             else hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, false, true>), grid, blk, 0, st, a);                                 \
@@ -650,6 +652,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
 /* timing probe only: device buffer of 64 u64 per workgroup (8 per wave: start, loop start, loop end, end, cycles at the tile
  * barrier, first-tile cycles, K tiles, realtime), or NULL to switch the probe off */
 extern "C" int vd_wino_set_probe(unsigned long long* buf) { g_probe = buf; return 0; }
+extern "C" int vd_wino_last_kernel(void) { return g_last_wino; }
 
 extern "C" int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf, float* ud, void* stream) {
     VD_REQUIRE(w_oihw && (uf || ud), "vd_wino_pack: null pointer");
@@ -960,9 +963,9 @@ extern "C" size_t vd_conv3x3_wgrad_wino_ws_bytes(int32_t nimg, int32_t H, int32_
     return ((size_t)2 * g.S * 9 * Cout * Cin + (size_t)g.S * Cout) * sizeof(float);
 }
 
-extern "C" int vd_conv3x3_wgrad_wino(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
-                                     int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
-                                     int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
+static int wgrad_wino_impl(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                           int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                           int32_t accumulate, float* ws, size_t ws_bytes, void* stream, int phases) {
     VD_REQUIRE(xin && dy && dw_oihw && ws, "vd_conv3x3_wgrad_wino: null operand");
     VD_REQUIRE(vd_conv3x3_wgrad_wino_supported(nimg, H, W, Cin, Cout, ldx, lddy), "vd_conv3x3_wgrad_wino: unsupported geometry "
                "nimg=%d H=%d W=%d Cin=%d Cout=%d (use vd_conv3x3_wgrad)", nimg, H, W, Cin, Cout);
@@ -983,14 +986,33 @@ extern "C" int vd_conv3x3_wgrad_wino(const float* xin, int64_t ldx, const float*
         if (dbias) hipLaunchKernelGGL((wino_wgrad_kernel<T, true>), grid, dim3(512), 0, st, a);  \
         else hipLaunchKernelGGL((wino_wgrad_kernel<T, false>), grid, dim3(512), 0, st, a);       \
     } while (0)
-    if (g.TWs == 16) VD_WG_LAUNCH(16);
-    else if (g.TWs == 8) VD_WG_LAUNCH(8);
-    else VD_WG_LAUNCH(4);
+    if (phases & 1) {
+        if (g.TWs == 16) VD_WG_LAUNCH(16);
+        else if (g.TWs == 8) VD_WG_LAUNCH(8);
+        else VD_WG_LAUNCH(4);
+        VD_LAUNCH_CHECK("wino_wgrad_kernel");
+    }
 #undef VD_WG_LAUNCH
-    VD_LAUNCH_CHECK("wino_wgrad_kernel");
-    const long long tot = (long long)Cout * Cin;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, 2 * g.S, Cout, Cin, Cout_w, Cin_w,
-                       dw_oihw, accumulate, a.cpart, g.S, dbias);
-    VD_LAUNCH_CHECK("wino_wgrad_reduce_kernel");
+    if (phases & 2) {
+        const long long tot = (long long)Cout * Cin;
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, 2 * g.S, Cout, Cin, Cout_w,
+                           Cin_w, dw_oihw, accumulate, a.cpart, g.S, dbias);
+        VD_LAUNCH_CHECK("wino_wgrad_reduce_kernel");
+    }
     return 0;
+}
+
+extern "C" int vd_conv3x3_wgrad_wino(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                                     int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                                     int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
+    return wgrad_wino_impl(xin, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw_oihw, dbias, Cin_w, Cout_w, accumulate, ws, ws_bytes, stream, 3);
+}
+
+/* the two kernels of vd_conv3x3_wgrad_wino as separate calls (per-kernel timing): phase 1 = slab planes, 2 = reduction.  The plan
+ * is a pure function of the arguments: the phases share no hidden state. */
+extern "C" int vd_conv3x3_wgrad_wino_phase(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
+                                           int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w,
+                                           int32_t Cout_w, int32_t accumulate, float* ws, size_t ws_bytes, int32_t phase, void* stream) {
+    VD_REQUIRE(phase == 1 || phase == 2, "vd_conv3x3_wgrad_wino_phase: phase must be 1 (slab planes) or 2 (reduce)");
+    return wgrad_wino_impl(xin, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw_oihw, dbias, Cin_w, Cout_w, accumulate, ws, ws_bytes, stream, phase);
 }

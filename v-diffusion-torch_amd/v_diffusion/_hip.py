@@ -45,6 +45,8 @@ _SIGNATURES = {
     "vd_conv3x3_wgrad_wino_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "vd_conv3x3_wgrad_wino_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "vd_conv3x3_wgrad_wino": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_conv3x3_wgrad_wino_phase": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _i32, _vp]),
+    "vd_wino_last_kernel": (C.c_int, []),
     "vd_wino_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
@@ -247,9 +249,12 @@ def wino_pack_batched(table, n, total_blocks):
 def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, stats_part=None):
     """Winograd F(2x2,3x3) form (see vd_conv3x3_wino); `flops` recorded = the direct convolution's (algorithmic) count, of
     which the matrix cores execute 4/9"""
-    with _TimedName("wino_conv_kernel<" + ("stats" if stats_part is not None else "plain") + ">", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _TimedName("wino_conv_kernel<{tw}, {ns}, {st}, false>", 2.0 * nimg * H * W * Cout * 9 * Cin) as t:
         _check(lib().vd_conv3x3_wino(ptr(x), ldx, ptr(U), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
                                      ptr(stats_part), stream()), "vd_conv3x3_wino")
+        if PROFILE is not None:
+            k = lib().vd_wino_last_kernel()
+            t.name = t.name.format(tw=k // 2000, ns=(k // 2) % 1000, st="true" if k & 1 else "false")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):
@@ -261,9 +266,17 @@ def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=
 def conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):
     nb = lib().vd_conv3x3_wgrad_wino_ws_bytes(nimg, H, W, Cin, Cout)
     ws = workspace(nb, x.device, "wgrad")
-    with _TimedName("wino_wgrad_kernel (+ wino_wgrad_reduce_kernel)", 2.0 * nimg * H * W * Cout * 9 * Cin):
-        _check(lib().vd_conv3x3_wgrad_wino(ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w,
-                                           int(accumulate), ws.data_ptr(), ws.numel() * 4, stream()), "vd_conv3x3_wgrad_wino")
+    args = (ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w, int(accumulate), ws.data_ptr(),
+            ws.numel() * 4)
+    if PROFILE is None:
+        _check(lib().vd_conv3x3_wgrad_wino(*args, stream()), "vd_conv3x3_wgrad_wino")
+        return
+    # per-kernel timing: the MFMA kernel and the plane reduction get their own event pairs (same kernels, same order)
+    tws = min(W // 2, 16)
+    with _TimedName(f"wino_wgrad_kernel<{tws}, {'true' if dbias is not None else 'false'}>", 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3_wgrad_wino_phase(*args, 1, stream()), "vd_conv3x3_wgrad_wino_phase")
+    with _TimedName("wino_wgrad_reduce_kernel", 0.0):
+        _check(lib().vd_conv3x3_wgrad_wino_phase(*args, 2, stream()), "vd_conv3x3_wgrad_wino_phase")
 
 
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None, direct=False):
