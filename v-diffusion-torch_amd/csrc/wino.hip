@@ -26,6 +26,7 @@
 //     of the output (16-lane butterflies) in the layout vd_gn_stats_from_partials expects (chunk = the wave's 64 pixels).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -81,7 +82,9 @@ __device__ __forceinline__ int b_swz(int row) { return (row >> 2) & 2; }
 // prefetch of the first U fragments of t+1, step 7.  One more barrier per item separates the epilogue's LDS exchange (in the
 // dead U stage) and the read of patch'(0) from the loader's next overwrite.
 constexpr int WINO_THREADS = 768;
-template <int TW, int NS, bool STATS, bool PROBE = false>
+// EXP != 0: timing experiments only (WRONG results; VD_WINO_EXP, tests/probe/wino_exp.py): 1 = no input-transform arithmetic,
+// 2 = also no patch reads, 3 = also no U-fragment reads, 4 = everything but no tile barrier in the compute waves' K loop
+template <int TW, int NS, bool STATS, bool PROBE = false, int EXP = 0>
 __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs p) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, tfirst = 0;
     if (PROBE) ts0 = __builtin_amdgcn_s_memtime();
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
                         if (nkt > 1) issue_A(1, pn ^ 1, pxn);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();                                // [kt]
+                    if (EXP != 4) __syncthreads();                  // [kt]
                 }
                 __syncthreads();                                    // [X] epilogue exchange
                 pb = (pb + nkt) & 1;
@@ -288,16 +291,24 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 f32x4 V[4];
-                V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
+                if (EXP >= 1 && EXP <= 3) { V[0] = tr[a][0]; V[1] = tr[a][1]; V[2] = tr[a][2]; V[3] = tr[a][3]; }
+                else { V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3]; }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int xi = 4 * a + b;
-                    if (xi < 7) {
+                    if (xi < 7 && !(EXP == 3)) {
                         // U fragments of step xi + 1 (one step = 8 MFMAs = 256+ cycles ahead of their use)
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb) ub[(xi + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 1) * 2 + cb) * 256);
                     }
-                    if (xi < 6) {
+                    if (xi < 6 && (EXP == 2 || EXP == 3)) {
+                        if (xi < 2) { trn[1][2 * xi] = tr[1][2 * xi]; trn[1][2 * xi + 1] = tr[1][2 * xi + 1]; }
+                        else if (xi < 4) { trn[0][2 * (xi - 2)] = tr[0][2 * (xi - 2)]; trn[0][2 * (xi - 2) + 1] = tr[0][2 * (xi - 2) + 1]; }
+                    } else if (xi < 6 && EXP == 1) {
+                        if (xi < 2) { trn[1][2 * xi] = *reinterpret_cast<const f32x4*>(pr2 + on + poff(2 * xi)); trn[1][2 * xi + 1] = *reinterpret_cast<const f32x4*>(pr2 + on + poff(2 * xi + 1)); }
+                        else if (xi < 4) { const int q0 = 2 * (xi - 2); trn[0][q0] = *reinterpret_cast<const f32x4*>(pr0 + on + poff(q0)); trn[0][q0 + 1] = *reinterpret_cast<const f32x4*>(pr0 + on + poff(q0 + 1)); }
+                        else { const int q0 = 2 * (xi - 4); const f32x4 r1a = *reinterpret_cast<const f32x4*>(pr1 + on + poff(q0)), r1b = *reinterpret_cast<const f32x4*>(pr1 + on + poff(q0 + 1)); asm volatile("" :: "v"(r1a), "v"(r1b)); }
+                    } else if (xi < 6) {
                         // 2 of the 12 patch reads of the next K tile (roles r2, r0 first: tr[0] early)
                         if (xi < 2) {
                             const f32x4 r2a = *reinterpret_cast<const f32x4*>(pr2 + on + poff(2 * xi)), r2b = *reinterpret_cast<const f32x4*>(pr2 + on + poff(2 * xi + 1));
@@ -317,11 +328,13 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
                         // every read of this K tile's stages is done: barrier, then the first U fragments of the next tile (or item)
                         unsigned long long tw = 0;
                         if (PROBE) tw = __builtin_amdgcn_s_memtime();
-                        __syncthreads();                            // [kt]
+                        if (EXP != 4) __syncthreads();              // [kt]
                         if (PROBE) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; if (kt == 0 && n == 0) tfirst = te - ts1; }
                         const float* bn = sB + (buf ^ 1) * B_STAGE + boff;
+                        if (EXP != 3) {
 #pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) ub[0][cb] = *reinterpret_cast<const f32x4*>(bn + cb * 256);
+                            for (int cb = 0; cb < 2; ++cb) ub[0][cb] = *reinterpret_cast<const f32x4*>(bn + cb * 256);
+                        }
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     }
 #pragma unroll
@@ -633,6 +646,15 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
         } else if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, true>), grid, blk, 0, st, a);                          \
         else hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, false>), grid, blk, 0, st, a);                                           \
     } while (0)
+    static const int exp_mode = getenv("VD_WINO_EXP") ? atoi(getenv("VD_WINO_EXP")) : 0;       // timing experiments (wrong results)
+    if (exp_mode && g.TW == 16 && g.NS <= 384 && !stats_part) {
+        if (exp_mode == 1) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 1>), grid, blk, 0, st, a);
+        else if (exp_mode == 2) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 2>), grid, blk, 0, st, a);
+        else if (exp_mode == 3) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 3>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 4>), grid, blk, 0, st, a);
+        VD_LAUNCH_CHECK("wino_conv_kernel(exp)");
+        return 0;
+    }
     // (tiles per row, patch slots): the square images of the shipped configs take the first form of each row
     if (g.TW == 16 && g.NS <= 384) VD_WINO_LAUNCH(16, 384);
     else if (g.TW == 8 && g.NS <= 384) VD_WINO_LAUNCH(8, 384);
