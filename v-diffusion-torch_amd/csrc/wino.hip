@@ -714,7 +714,7 @@ constexpr int WG_PPW = (WG_PIECES + 7) / 8;         // 7 DMA pieces per wave (th
 
 struct WgradArgs {
     const float* x; long long ldx; const float* dy; long long lddy;
-    float* slabs;                      // [2 * S][9][Cout][Cin]
+    float* slabs;                      // [S][9][Cout][Cin]
     float* cpart;                      // [S][Cout] bias-gradient partials, or NULL
     int nimg, H, W, Cin, Cout;
     int TW, TH, TPI, lgTW, lgTPI;
@@ -731,7 +731,21 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kq = lane >> 4;
     const int ah = wave >> 2, mh = (wave >> 1) & 1, nh = wave & 1;
-    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, z = blockIdx.z;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (linear id % 8).  All (co, ci) blocks of one slab read
+    // the same tiles of x and dY: put them on ONE XCD (slab z lives on XCD z % 8) so those tiles cross the fabric once per slab
+    // instead of once per channel block (PMC: 1.02 GB per launch against 0.27 GB of x + dY).  Any placement is correct.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned nb = gridDim.x * gridDim.y, S = gridDim.z, T = nb * S;
+        const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (S % 8 == 0) {
+            const unsigned xcd = lin % 8, slot = lin / 8;           // slot-th workgroup of that XCD
+            const unsigned zz = xcd + 8 * (slot / nb), blk = slot % nb;
+            bz = (int)zz; bx = (int)(blk % gridDim.x); by = (int)(blk / gridDim.x);
+        }
+        (void)T;
+    }
+    const int ci0 = bx * 64, co0 = by * 64, z = bz;
     const int st_begin = z * p.per, st_end = min(st_begin + p.per, p.nstages);
 
     // ---------------- DMA: per-lane source offsets relative to the stage (constant) and border classes
@@ -802,7 +816,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[xi][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x2 bsum = {0.f, 0.f};
-    const bool do_bias = DBIAS && ah == 0 && nh == 0 && blockIdx.x == 0;
+    const bool do_bias = DBIAS && ah == 0 && nh == 0 && bx == 0;
 
     auto kstep = [&](const unsigned char* sb, const int ks) {
         constexpr int dummy = 0; (void)dummy;
@@ -869,13 +883,15 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
     // ---------------- epilogue: partial G^T dU G of this wave's two rows a.   G^T = [1 .5 .5 0 ; 0 .5 -.5 0 ; 0 .5 .5 1]
     // true dU[a][b] = sa(a) sb(b) acc with sa(3) = sb(3) = -1 (folded signs)
     // lane (n = lm, rq = kq), register r: co = co0 + 32 mh + 2 (4 rq + r) + mb, ci = ci0 + 32 nh + 2 n + nb
-    float* plane = p.slabs + (long long)(2 * z + ah) * 9 * p.Cout * p.Cin;
+    // The xi-half-1 wave of every (co half, ci half) pair hands its partial to its partner through LDS (the stages are dead: the K
+    // loop ended on a barrier), which adds and writes ONE plane per slab -- half the plane traffic of writing both.
+    float* plane = p.slabs + (long long)z * 9 * p.Cout * p.Cin;
+    f32x2* xch = reinterpret_cast<f32x2*>(smem) + (size_t)(mh * 2 + nh) * (4 * 9 * 64);        // [pair][r][k = 3i+j][lane]
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < 2; ++mb) {
+        f32x2 w9[4][3][3];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = co0 + 32 * mh + 2 * (4 * kq + r) + mb;
-            f32x2 w9[3][3];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 float c[2][3];
@@ -888,19 +904,32 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    if (ah == 0) { const float h = 0.5f * c[1][j]; w9[0][j][nb] = c[0][j] + h; w9[1][j][nb] = h; w9[2][j][nb] = h; }
-                    else { const float h = 0.5f * c[0][j]; w9[0][j][nb] = h; w9[1][j][nb] = -h; w9[2][j][nb] = h - c[1][j]; }
+                    if (ah == 0) { const float h = 0.5f * c[1][j]; w9[r][0][j][nb] = c[0][j] + h; w9[r][1][j][nb] = h; w9[r][2][j][nb] = h; }
+                    else { const float h = 0.5f * c[0][j]; w9[r][0][j][nb] = h; w9[r][1][j][nb] = -h; w9[r][2][j][nb] = h - c[1][j]; }
                 }
             }
+        }
+        if (ah != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) xch[(r * 9 + k) * 64 + lane] = w9[r][k / 3][k % 3];
+        }
+        __syncthreads();
+        if (ah == 0) {
             const int ci = ci0 + 32 * nh + 2 * lm;
-            if (co < p.Cout && ci < p.Cin) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + 32 * mh + 2 * (4 * kq + r) + mb;
+                if (co < p.Cout && ci < p.Cin) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        *reinterpret_cast<f32x2*>(plane + ((long long)(3 * i + j) * p.Cout + co) * p.Cin + ci) = w9[i][j];
+                    for (int k = 0; k < 9; ++k)
+                        *reinterpret_cast<f32x2*>(plane + ((long long)k * p.Cout + co) * p.Cin + ci) = w9[r][k / 3][k % 3] + xch[(r * 9 + k) * 64 + lane];
+                }
             }
         }
+        __syncthreads();
+    }
     if (DBIAS && do_bias && p.cpart) {
         // sum over the 4 tiles of a K step (lanes with equal lm): lanes kq = 0 write channels co0 + 32 mh + 2 lm + {0, 1}
 #pragma unroll
@@ -915,7 +944,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
     }
 }
 
-// dw[co][ci][tap] (+)= sum over the 2 S planes (fixed order); dbias[co] (+)= sum over the S partial rows
+// dw[co][ci][tap] (+)= sum over the S planes (fixed order); dbias[co] (+)= sum over the S partial rows
 __global__ void wino_wgrad_reduce_kernel(const float* slabs, int planes, int Cout, int Cin, int Cout_w, int Cin_w, float* dw, int accumulate,
                                          const float* cpart, int S, float* dbias) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -982,7 +1011,7 @@ extern "C" int vd_conv3x3_wgrad_wino_supported(int32_t nimg, int32_t H, int32_t 
 extern "C" size_t vd_conv3x3_wgrad_wino_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     const WgPlan g = wgrad_plan_wino(nimg, H, W, Cin, Cout);
     if (!g.ok) return 0;
-    return ((size_t)2 * g.S * 9 * Cout * Cin + (size_t)g.S * Cout) * sizeof(float);
+    return ((size_t)g.S * 9 * Cout * Cin + (size_t)g.S * Cout) * sizeof(float);
 }
 
 static int wgrad_wino_impl(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
@@ -997,7 +1026,7 @@ static int wgrad_wino_impl(const float* xin, int64_t ldx, const float* dy, int64
     const WgPlan g = wgrad_plan_wino(nimg, H, W, Cin, Cout);
     WgradArgs a = {};
     a.x = xin; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.slabs = ws;
-    a.cpart = dbias ? ws + (size_t)2 * g.S * 9 * Cout * Cin : nullptr;
+    a.cpart = dbias ? ws + (size_t)g.S * 9 * Cout * Cin : nullptr;
     a.nimg = nimg; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.TW = g.TW; a.TH = g.TH; a.TPI = g.TPI; a.lgTW = ilog2(g.TW); a.lgTPI = ilog2(g.TPI);
     a.nstages = g.nstages; a.per = g.per;
@@ -1017,7 +1046,7 @@ static int wgrad_wino_impl(const float* xin, int64_t ldx, const float* dy, int64
 #undef VD_WG_LAUNCH
     if (phases & 2) {
         const long long tot = (long long)Cout * Cin;
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, 2 * g.S, Cout, Cin, Cout_w,
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, g.S, Cout, Cin, Cout_w,
                            Cin_w, dw_oihw, accumulate, a.cpart, g.S, dbias);
         VD_LAUNCH_CHECK("wino_wgrad_reduce_kernel");
     }
