@@ -688,7 +688,9 @@ WINO_CASES = [  # nimg, H, W, Cin, Cout, ldx_extra, ldy_extra      (geometries: 
     (1, 64, 64, 16, 32, 0, 0),       # 32 tiles per row: half a tile row per wave
     (2, 16, 32, 32, 32, 0, 0),       # non-square
     (1, 8, 128, 16, 20, 0, 0),       # 64 tiles per row (largest patch image)
-    (4, 32, 32, 256, 256, 0, 0), (8, 16, 16, 512, 256, 0, 0), (16, 8, 8, 256, 256, 0, 0), (1, 64, 64, 192, 192, 0, 0)]
+    (4, 32, 32, 256, 256, 0, 0), (8, 16, 16, 512, 256, 0, 0), (16, 8, 8, 256, 256, 0, 0), (1, 64, 64, 192, 192, 0, 0),
+    (10, 32, 32, 32, 96, 0, 0),      # 40 tile groups x 3 channel blocks = 120 work items (one ragged round of persistent workgroups)
+    (9, 32, 32, 16, 288, 0, 0)]      # 36 x 9 = 324 items: one full round of 256 (XCD-permuted ids) + a ragged one (plain ids)
 
 
 @pytest.mark.parametrize("case", WINO_CASES)

@@ -111,17 +111,9 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
     // neighbouring items (channel blocks fastest: they share the input patch in that XCD's L2)
     auto item_of = [&](int n, int& tbx, int& tby) -> bool {
         int t = n * G + w;
-        if ((G & 7) == 0) t = n * G + (w & 7) * (G >> 3) + (w >> 3);
-        if (t >= nitems) {                      // ragged last round: the permuted id may overshoot while a plain one would not
-            t = n * G + w;
-            if ((G & 7) == 0) {
-                // ids [n G, nitems) in permuted order: take the w-th valid one
-                const int valid = nitems - n * G;
-                if (w >= valid) return false;
-                t = n * G + w;
-            }
-            if (t >= nitems) return false;
-        }
+        // (only in FULL rounds: a ragged last round keeps the plain ids, or permuted and plain ids would collide)
+        if ((G & 7) == 0 && (n + 1) * G <= nitems) t = n * G + (w & 7) * (G >> 3) + (w >> 3);
+        if (t >= nitems) return false;
         tbx = t % p.ncb; tby = t / p.ncb;
         return true;
     };
