@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "v-diffusion-torch_amd"))
 from v_diffusion import _hip as H
 
 DEV = "cuda"
-names = {0: "full kernel", 1: "no transform arithmetic", 2: "+ no patch reads", 3: "+ no U-fragment reads", 4: "full, no tile barrier"}
+names = {0: "full kernel", 1: "no transform arithmetic", 2: "+ no patch reads", 3: "+ no U-fragment reads", 4: "full, no tile barrier", 5: "MFMA + epilogue skeleton (no LDS reads, no DMA)"}
 e = int(os.environ.get("VD_WINO_EXP", "0"))
 for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256)):
     x = torch.randn(nimg, Hh, Ww, Cin, device=DEV)

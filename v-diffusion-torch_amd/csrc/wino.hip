@@ -83,7 +83,8 @@ __device__ __forceinline__ int b_swz(int row) { return (row >> 2) & 2; }
 // dead U stage) and the read of patch'(0) from the loader's next overwrite.
 constexpr int WINO_THREADS = 768;
 // EXP != 0: timing experiments only (WRONG results; VD_WINO_EXP, tests/probe/wino_exp.py): 1 = no input-transform arithmetic,
-// 2 = also no patch reads, 3 = also no U-fragment reads, 4 = everything but no tile barrier in the compute waves' K loop
+// 2 = also no patch reads, 3 = also no U-fragment reads, 4 = everything but no tile barrier in the compute waves' K loop,
+// 5 = like 3 and the loaders issue no DMA (the MFMA + epilogue skeleton alone)
 template <int TW, int NS, bool STATS, bool PROBE = false, int EXP = 0>
 __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs p) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, tfirst = 0;
@@ -191,9 +192,11 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
                 __syncthreads();                                    // [P2] the compute waves have read patch(0) out of sA[pb]
                 for (int kt = 0; kt < nkt; ++kt) {
                     const int buf = (pb + kt) & 1;
-                    if (kt + 1 < nkt) issue_B(kt + 1, buf ^ 1, vb0);
-                    if (kt + 2 < nkt) issue_A(kt + 2, buf, pxo);
-                    if (next && kt == nkt - 1) {                    // head of the next item into the stages this item has left
+                    if (EXP != 5) {
+                        if (kt + 1 < nkt) issue_B(kt + 1, buf ^ 1, vb0);
+                        if (kt + 2 < nkt) issue_A(kt + 2, buf, pxo);
+                    }
+                    if (next && kt == nkt - 1 && EXP != 5) {        // head of the next item into the stages this item has left
                         const int pn = (pb + nkt) & 1;
                         issue_B(0, pn, vb0n);
                         issue_A(0, pn, pxn);
@@ -283,17 +286,17 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 f32x4 V[4];
-                if (EXP >= 1 && EXP <= 3) { V[0] = tr[a][0]; V[1] = tr[a][1]; V[2] = tr[a][2]; V[3] = tr[a][3]; }
+                if ((EXP >= 1 && EXP <= 3) || EXP == 5) { V[0] = tr[a][0]; V[1] = tr[a][1]; V[2] = tr[a][2]; V[3] = tr[a][3]; }
                 else { V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3]; }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int xi = 4 * a + b;
-                    if (xi < 7 && !(EXP == 3)) {
+                    if (xi < 7 && !(EXP == 3 || EXP == 5)) {
                         // U fragments of step xi + 1 (one step = 8 MFMAs = 256+ cycles ahead of their use)
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb) ub[(xi + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 1) * 2 + cb) * 256);
                     }
-                    if (xi < 6 && (EXP == 2 || EXP == 3)) {
+                    if (xi < 6 && (EXP == 2 || EXP == 3 || EXP == 5)) {
                         if (xi < 2) { trn[1][2 * xi] = tr[1][2 * xi]; trn[1][2 * xi + 1] = tr[1][2 * xi + 1]; }
                         else if (xi < 4) { trn[0][2 * (xi - 2)] = tr[0][2 * (xi - 2)]; trn[0][2 * (xi - 2) + 1] = tr[0][2 * (xi - 2) + 1]; }
                     } else if (xi < 6 && EXP == 1) {
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
                         if (EXP != 4) __syncthreads();              // [kt]
                         if (PROBE) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; if (kt == 0 && n == 0) tfirst = te - ts1; }
                         const float* bn = sB + (buf ^ 1) * B_STAGE + boff;
-                        if (EXP != 3) {
+                        if (EXP != 3 && EXP != 5) {
 #pragma unroll
                             for (int cb = 0; cb < 2; ++cb) ub[0][cb] = *reinterpret_cast<const f32x4*>(bn + cb * 256);
                         }
@@ -643,6 +646,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
         if (exp_mode == 1) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 1>), grid, blk, 0, st, a);
         else if (exp_mode == 2) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 2>), grid, blk, 0, st, a);
         else if (exp_mode == 3) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 3>), grid, blk, 0, st, a);
+        else if (exp_mode == 5) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 5>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 4>), grid, blk, 0, st, a);
         VD_LAUNCH_CHECK("wino_conv_kernel(exp)");
         return 0;
