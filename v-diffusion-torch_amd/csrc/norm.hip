@@ -8,6 +8,7 @@
 //   finalize     : tiny kernels turning partials into per-(image,group) statistics / per-(image,channel) tables
 //   apply        : float4 elementwise pass reading x once (+ an L1/L2-resident coefficient table)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -632,7 +633,11 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
         static const bool two_pass = getenv("VD_GN_TWO_PASS") != nullptr;        // A/B switch for profiling
         const int CS = fused_slab(C, G);
         if (!two_pass && CS > 0 && nimg <= 65535) {
-            const int TPB = HW * (CS / 4) >= 1024 ? 1024 : 256;
+            // 256-thread workgroups (8+ per CU: their load / reduce / store phases overlap) whenever a slab fits 8 float4 pairs per
+            // thread, i.e. up to 2048 pairs (16x16 images at 32-channel slabs); 1024 threads only for the larger slabs
+            // (VD_GN_TPB=1024 restores the round-1 choice for A/B runs)
+            static const bool big = getenv("VD_GN_TPB") && atoi(getenv("VD_GN_TPB")) == 1024;
+            const int TPB = (HW * (CS / 4) > 2048 || (big && HW * (CS / 4) >= 1024)) ? 1024 : 256;
             const int rows = TPB / (CS / 4);
             const int npt = (int)((HW + rows - 1) / rows);
             if (npt <= 8) {
