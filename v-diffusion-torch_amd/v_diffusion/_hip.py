@@ -249,7 +249,7 @@ def wino_pack_batched(table, n, total_blocks):
 def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, stats_part=None):
     """Winograd F(2x2,3x3) form (see vd_conv3x3_wino); `flops` recorded = the direct convolution's (algorithmic) count, of
     which the matrix cores execute 4/9"""
-    with _TimedName("wino_conv_kernel<{tw}, {ns}, {st}, false>", 2.0 * nimg * H * W * Cout * 9 * Cin) as t:
+    with _TimedName("wino_conv_kernel<{tw}, {ns}, {st}, false, 0>", 2.0 * nimg * H * W * Cout * 9 * Cin) as t:
         _check(lib().vd_conv3x3_wino(ptr(x), ldx, ptr(U), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
                                      ptr(stats_part), stream()), "vd_conv3x3_wino")
         if PROFILE is not None:
