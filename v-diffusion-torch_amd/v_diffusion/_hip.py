@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvdiff_hip.so")
+LIB_PATH = os.environ.get("VDIFF_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvdiff_hip.so")   # (override: A/B builds)
 
 ROW, COL, IM2COL = 0, 1, 2
 RS_NONE, RS_DOWN, RS_UP = 0, 1, 2
