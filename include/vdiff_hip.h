@@ -208,6 +208,18 @@ int vd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, int32_t a
 int vd_softmax_rows(float* s, int64_t rows, int32_t L, void* stream);
 int vd_softmax_rows_bwd(const float* p, float* dp, int64_t rows, int32_t L, float alpha, void* stream);
 
+/* fused scaled-dot-product attention (BaseAttentionBlock.scaled_dot_product, unet.py:55-64, and its autograd): o = softmax(scale q k^T) v
+ * per (image b, head h) without the [B, nh, L, L] logits in HBM.  Operands are rows of the qkv projection:
+ * x[(b L + l) ld + h hd + d].  Served: L % 64 == 0 and hd in {64, 128, 256} forward, {64, 128} backward (vd_attn_supported);
+ * everything else takes vd_gemm -> vd_softmax_rows -> vd_gemm.  lse [B nh L] (forward output, may be NULL when no backward
+ * follows) and delta [B nh L] (backward scratch) are opaque to the caller.  Fixed summation order: bitwise reproducible. */
+int vd_attn_supported(int32_t L, int32_t hd, int32_t backward);
+int vd_attn_fwd(const float* q, const float* k, const float* v, int64_t ld, float* o, int64_t ldo, float* lse, int32_t B,
+                int32_t nh, int32_t L, int32_t hd, float scale, void* stream);
+int vd_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo, const float* dout,
+                int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldd, int32_t B,
+                int32_t nh, int32_t L, int32_t hd, float scale, void* stream);
+
 /* layout changes at the boundary of the NCHW call surface */
 int vd_nchw_to_nhwc(const float* x, float* y, int32_t nimg, int32_t C, int32_t H, int32_t W, int64_t ldy, void* stream);
 int vd_nhwc_to_nchw(const float* x, int64_t ldx, float* y, int32_t nimg, int32_t C, int32_t H, int32_t W, void* stream);

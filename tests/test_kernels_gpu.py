@@ -481,6 +481,77 @@ def test_softmax_rows(H, L):
     close(dpd, ss.grad, None, floor=3e-6, name="softmax bwd")
 
 
+ATTN_CASES = [(2, 2, 256, 64), (1, 1, 1024, 64), (3, 1, 64, 64), (2, 1, 128, 128), (1, 2, 320, 128), (2, 1, 64, 256), (1, 1, 1024, 256)]
+
+
+def _attn_ref(qkv, B, nh, L, hd, dtype):
+    """softmax(q k^T / sqrt(hd)) v per (image, head) on the packed [B, L, 3 nh hd] projection (unet.py:55-64)"""
+    x = qkv.to(dtype).reshape(B, L, 3, nh, hd)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))          # [B, nh, L, hd]
+    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B, L, nh * hd)
+
+
+@pytest.mark.parametrize("B,nh,L,hd", ATTN_CASES)
+def test_attn_fused_forward(H, B, nh, L, hd):
+    assert H.attn_supported(L, hd, False)
+    hid = nh * hd
+    qkv = rnd(B, L, 3 * hid, seed=L + hd) * 1.5                            # logits of std ~2: a softmax with real contrast
+    ref64, ref32 = _attn_ref(qkv, B, nh, L, hd, torch.float64), _attn_ref(qkv, B, nh, L, hd, torch.float32)
+    qd = qkv.to(DEV)
+    o = torch.full((B, L, hid + 4), 7.0, device=DEV)                        # ldo > hid: the padding must survive
+    lse = torch.empty(B * nh * L, device=DEV)
+    flat = qd.reshape(-1)
+    H.attn_fwd(flat[0:], flat[hid:], flat[2 * hid:], 3 * hid, o, hid + 4, lse, B, nh, L, hd, 1.0 / math.sqrt(hd))
+    torch.cuda.synchronize()
+    close(o[..., :hid], ref64, ref32, floor=3e-6, name="attn fwd")
+    assert (o[..., hid:] == 7.0).all()
+    # log-sum-exp (log2 domain) against the definition
+    x = qkv.double().reshape(B, L, 3, nh, hd)
+    s = (x[:, :, 0].permute(0, 2, 1, 3) @ x[:, :, 1].permute(0, 2, 3, 1)) / math.sqrt(hd)
+    close(lse.reshape(B, nh, L), torch.logsumexp(s, -1) * math.log2(math.e), None, floor=3e-6, name="attn lse")
+    # lse = NULL (no backward follows) gives the same output, bit for bit, and so does a second run
+    o2 = torch.full((B, L, hid + 4), 7.0, device=DEV)
+    H.attn_fwd(flat[0:], flat[hid:], flat[2 * hid:], 3 * hid, o2, hid + 4, None, B, nh, L, hd, 1.0 / math.sqrt(hd))
+    assert torch.equal(o, o2)
+
+
+@pytest.mark.parametrize("B,nh,L,hd", [c for c in ATTN_CASES if c[3] <= 128])
+def test_attn_fused_backward(H, B, nh, L, hd):
+    assert H.attn_supported(L, hd, True)
+    hid = nh * hd
+    qkv = rnd(B, L, 3 * hid, seed=L + hd + 1) * 1.5
+    do = rnd(B, L, hid, seed=3)
+    g64 = qkv.double().requires_grad_(True)
+    _attn_ref(g64, B, nh, L, hd, torch.float64).backward(do.double())
+    g32 = qkv.clone().requires_grad_(True)
+    _attn_ref(g32, B, nh, L, hd, torch.float32).backward(do)
+    qd, dod = qkv.to(DEV), do.to(DEV)
+    flat = qd.reshape(-1)
+    o = torch.empty(B, L, hid, device=DEV)
+    lse, delta = torch.empty(B * nh * L, device=DEV), torch.empty(B * nh * L, device=DEV)
+    sc = 1.0 / math.sqrt(hd)
+    H.attn_fwd(flat[0:], flat[hid:], flat[2 * hid:], 3 * hid, o, hid, lse, B, nh, L, hd, sc)
+    dqkv = torch.full((B, L, 3 * hid), 5.0, device=DEV)
+    dflat = dqkv.reshape(-1)
+    H.attn_bwd(flat[0:], flat[hid:], flat[2 * hid:], 3 * hid, o, hid, dod, hid, lse, delta, dflat[0:], dflat[hid:], dflat[2 * hid:],
+               3 * hid, B, nh, L, hd, sc)
+    torch.cuda.synchronize()
+    close(dqkv, g64.grad, g32.grad, floor=3e-6, name="attn bwd")
+    dqkv2 = torch.empty_like(dqkv)
+    d2 = dqkv2.reshape(-1)
+    H.attn_bwd(flat[0:], flat[hid:], flat[2 * hid:], 3 * hid, o, hid, dod, hid, lse, delta, d2[0:], d2[hid:], d2[2 * hid:], 3 * hid,
+               B, nh, L, hd, sc)
+    assert torch.equal(dqkv, dqkv2), "fused attention backward is not bitwise reproducible"
+
+
+def test_attn_unsupported_shapes_are_refused(H):
+    assert not H.attn_supported(100, 64, False) and not H.attn_supported(256, 32, False) and not H.attn_supported(256, 256, True)
+    x = torch.zeros(1, 100, 192, device=DEV)
+    with pytest.raises(H.HipError):
+        H.attn_fwd(x, x, x, 192, x, 192, None, 1, 1, 100, 64, 0.125)
+
+
 def test_layout_roundtrip(H):
     x = rnd(3, 3, 8, 8, seed=1)
     y = torch.full((3, 8, 8, 4), 9.0, device=DEV)

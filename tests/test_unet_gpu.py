@@ -116,7 +116,15 @@ def test_full_size_unet_vs_golden(vd, golden_dir, name, cfgname, B, R, label):
     # eval-mode inference path (no tape) gives the same numbers
     with torch.no_grad():
         out2 = model(x.to(DEV), t.to(DEV), y.to(DEV))
-    assert torch.equal(out2, out.detach())
+    from v_diffusion import _hip
+    hd = cfg.get("head_dim") or cfg["hid_channels"]
+    if _hip.attn_supported(1024, hd, False) and not _hip.attn_supported(1024, hd, True):
+        # head dim 256: the fused attention serves the forward-only pass, the training step keeps the three launches --
+        # two summation orders, both held to the reference's tolerance
+        err2 = np.abs(out2.cpu().numpy() - g["out"]).max()
+        assert err2 <= 2e-5 + 1e-4 * 1e-1 * scale, f"no-tape output differs from the reference by {err2:.3e}"
+    else:
+        assert torch.equal(out2, out.detach())
 
 
 def test_shard_gradients_sum_to_full_batch(vd):
@@ -391,8 +399,11 @@ def test_hot_path_trainer_matches_torch_optimizer(vd):
         assert abs(float(loss_fast) - float(loss)) <= 1e-5 * max(abs(float(loss)), 1.0)
     ema = tr.flat.ema_state_dict()
     for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        assert (p - q).abs().max().item() <= 2e-5 * max(q.abs().max().item(), 1e-3), k
-        assert (ema[k] - shadow[k]).abs().max().item() <= 2e-5 * max(q.abs().max().item(), 1e-3), k
+        # the key third of an attention block's proj_in.bias has an exactly-zero gradient (softmax is invariant to a constant added
+        # to every key): what reaches Adam there is rounding noise of the attention backward, amplified to ~lr by g/sqrt(v)
+        tol = 2e-5 * max(q.abs().max().item(), 1e-3) + (2e-5 if k.endswith("proj_in.bias") else 0.0)
+        assert (p - q).abs().max().item() <= tol, k
+        assert (ema[k] - shadow[k]).abs().max().item() <= tol, k
     # the module still round-trips through state_dict in the reference layout
     sd = model.state_dict()
     assert list(sd.keys()) == list(ref.state_dict().keys())

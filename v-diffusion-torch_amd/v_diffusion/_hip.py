@@ -67,6 +67,9 @@ _SIGNATURES = {
     "vd_silu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "vd_softmax_rows": (C.c_int, [_vp, _i64, _i32, _vp]),
     "vd_softmax_rows_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
+    "vd_attn_supported": (C.c_int, [_i32, _i32, _i32]),
+    "vd_attn_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "vd_attn_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
     "vd_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "vd_nhwc_to_nchw": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vd_images_to_uint8_hwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -405,6 +408,27 @@ def softmax_rows(s, rows, L):
 
 def softmax_rows_bwd(p, dp, rows, L, alpha):
     _check(lib().vd_softmax_rows_bwd(ptr(p), ptr(dp), rows, L, alpha, stream()), "vd_softmax_rows_bwd")
+
+
+FUSED_ATTN = os.environ.get("VD_FUSED_ATTN", "1") != "0"     # A/B switch: 0 keeps the three-launch attention everywhere
+
+
+def attn_supported(L, hd, backward):
+    return FUSED_ATTN and bool(lib().vd_attn_supported(L, hd, int(backward)))
+
+
+def attn_fwd(q, k, v, ld, o, ldo, lse, B, nh, L, hd, scale):
+    """fused softmax(scale q k^T) v; FLOPs recorded = the two products (4 L^2 hd per image and head)"""
+    with _TimedName(f"attn_fwd_kernel<{hd}>", 4.0 * B * nh * L * L * hd):
+        _check(lib().vd_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(o), ldo, ptr(lse), B, nh, L, hd, scale, stream()), "vd_attn_fwd")
+
+
+def attn_bwd(q, k, v, ld, o, ldo, dout, lddo, lse, delta, dq, dk, dv, ldd, B, nh, L, hd, scale):
+    """backward of attn_fwd (recomputes the probabilities); FLOPs recorded = the four products of the unfused backward
+    (8 L^2 hd per image and head) -- the kernels execute seven"""
+    with _TimedName(f"attn_bwd_kernels<{hd}>", 8.0 * B * nh * L * L * hd):
+        _check(lib().vd_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(o), ldo, ptr(dout), lddo, ptr(lse), ptr(delta), ptr(dq), ptr(dk),
+                                 ptr(dv), ldd, B, nh, L, hd, scale, stream()), "vd_attn_bwd")
 
 
 def nchw_to_nhwc(x, y, nimg, Cc, H, W, ldy):

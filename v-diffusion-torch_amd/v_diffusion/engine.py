@@ -478,15 +478,23 @@ class UNetEngine:
         H.gemm(xn, mod.proj_in.weight, qkv, B * L, 3 * hid, C, a_kind=H.ROW, b_kind=H.ROW, lda=C, ldb=C, ldc=3 * hid,
                bias=mod.proj_in.bias)
         ld = 3 * hid
-        S = self._new(x, B, nh, L, L)
         alpha = 1.0 / math.sqrt(hd)
         q, k, v = qkv[0, 0, 0:], qkv[0, 0, hid:], qkv[0, 0, 2 * hid:]
-        H.gemm(q, k, S, L, L, hd, a_kind=H.ROW, b_kind=H.ROW, lda=ld, ldb=ld, ldc=L, batch=B * nh, nh=nh, sA=(L * ld, hd),
-               sB=(L * ld, hd), sC=(nh * L * L, L * L), alpha=alpha)
-        H.softmax_rows(S, B * nh * L, L)
         O = self._new(x, B, L, hid)
-        H.gemm(S, v, O, L, hd, L, a_kind=H.ROW, b_kind=H.COL, lda=L, ldb=ld, ldc=hid, batch=B * nh, nh=nh, sA=(nh * L * L, L * L),
-               sB=(L * ld, hd), sC=(L * hid, hd))
+        S = lse = None
+        if H.attn_supported(L, hd, tape is not None):
+            # fused kernels (csrc/attn.hip): the [B, nh, L, L] maps never reach HBM; the backward recomputes them from the
+            # per-row log-sum-exp.  (hd = 256 is served forward-only: sampling; its training step keeps the three launches.)
+            if tape is not None:
+                lse = self._new(x, B * nh * L)
+            H.attn_fwd(q, k, v, ld, O, hid, lse, B, nh, L, hd, alpha)
+        else:
+            S = self._new(x, B, nh, L, L)
+            H.gemm(q, k, S, L, L, hd, a_kind=H.ROW, b_kind=H.ROW, lda=ld, ldb=ld, ldc=L, batch=B * nh, nh=nh, sA=(L * ld, hd),
+                   sB=(L * ld, hd), sC=(nh * L * L, L * L), alpha=alpha)
+            H.softmax_rows(S, B * nh * L, L)
+            H.gemm(S, v, O, L, hd, L, a_kind=H.ROW, b_kind=H.COL, lda=L, ldb=ld, ldc=hid, batch=B * nh, nh=nh, sA=(nh * L * L, L * L),
+                   sB=(L * ld, hd), sC=(L * hid, hd))
         pd = self._part(x, B, L, C)
         if pd is not None and L % 64:
             pd = None                                     # the plain GEMM picks its own row tile: only ask when any tile fits
@@ -494,7 +502,7 @@ class UNetEngine:
                bias=mod.proj_out.bias, R=x, ldr=ldx, stats=pd, stats_hw=L)
         out_parts = self._parts(pd, C, L)
         if tape is not None:
-            tape[prefix] = dict(x=x, coef=coef, xn=xn, qkv=qkv, P=S, O=O)
+            tape[prefix] = dict(x=x, coef=coef, xn=xn, qkv=qkv, P=S, O=O, lse=lse)
         return out_parts
 
     def _attn_bwd(self, mod, prefix, ctx, dy, dx, dx_accumulate, G):
@@ -513,17 +521,22 @@ class UNetEngine:
         q, k, v = qkv[0, 0, 0:], qkv[0, 0, hid:], qkv[0, 0, 2 * hid:]
         dq, dk, dv = dqkv[0, 0, 0:], dqkv[0, 0, hid:], dqkv[0, 0, 2 * hid:]
         sP, sQ, sO = (nh * L * L, L * L), (L * ld, hd), (L * hid, hd)
-        # dV[j][d] = sum_l P[l][j] dO[l][d]
-        H.gemm(P, dO, dv, L, hd, L, a_kind=H.COL, b_kind=H.COL, lda=L, ldb=hid, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sO, sC=sQ)
-        # dP[l][j] = sum_d dO[l][d] V[j][d]
-        dP = self._new(x, B, nh, L, L)
-        H.gemm(dO, v, dP, L, L, hd, a_kind=H.ROW, b_kind=H.ROW, lda=hid, ldb=ld, ldc=L, batch=B * nh, nh=nh, sA=sO, sB=sQ, sC=sP)
         alpha = 1.0 / math.sqrt(hd)
-        H.softmax_rows_bwd(P, dP, B * nh * L, L, alpha)                 # dP <- dS (already scaled by 1/sqrt(hd))
-        # dQ[l][d] = sum_j dS[l][j] K[j][d] ; dK[j][d] = sum_l dS[l][j] Q[l][d]
-        H.gemm(dP, k, dq, L, hd, L, a_kind=H.ROW, b_kind=H.COL, lda=L, ldb=ld, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sQ, sC=sQ)
-        H.gemm(dP, q, dk, L, hd, L, a_kind=H.COL, b_kind=H.COL, lda=L, ldb=ld, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sQ, sC=sQ)
-        del dP, dO
+        if P is None:
+            # the forward ran fused: probabilities are recomputed from the saved log-sum-exp
+            H.attn_bwd(q, k, v, ld, O, hid, dO, hid, ctx["lse"], self._new(x, B * nh * L), dq, dk, dv, ld, B, nh, L, hd, alpha)
+        else:
+            # dV[j][d] = sum_l P[l][j] dO[l][d]
+            H.gemm(P, dO, dv, L, hd, L, a_kind=H.COL, b_kind=H.COL, lda=L, ldb=hid, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sO, sC=sQ)
+            # dP[l][j] = sum_d dO[l][d] V[j][d]
+            dP = self._new(x, B, nh, L, L)
+            H.gemm(dO, v, dP, L, L, hd, a_kind=H.ROW, b_kind=H.ROW, lda=hid, ldb=ld, ldc=L, batch=B * nh, nh=nh, sA=sO, sB=sQ, sC=sP)
+            H.softmax_rows_bwd(P, dP, B * nh * L, L, alpha)                 # dP <- dS (already scaled by 1/sqrt(hd))
+            # dQ[l][d] = sum_j dS[l][j] K[j][d] ; dK[j][d] = sum_l dS[l][j] Q[l][d]
+            H.gemm(dP, k, dq, L, hd, L, a_kind=H.ROW, b_kind=H.COL, lda=L, ldb=ld, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sQ, sC=sQ)
+            H.gemm(dP, q, dk, L, hd, L, a_kind=H.COL, b_kind=H.COL, lda=L, ldb=ld, ldc=ld, batch=B * nh, nh=nh, sA=sP, sB=sQ, sC=sQ)
+            del dP
+        del dO
         # proj_in
         H.gemm(dqkv, xn, G[prefix + ".proj_in.weight"], ld, C, M, a_kind=H.COL, b_kind=H.COL, lda=ld, ldb=C, ldc=C,
                splitk=_splitk(ld, C, M), colsum=G[prefix + ".proj_in.bias"])
