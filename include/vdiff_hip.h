@@ -219,6 +219,10 @@ int vd_attn_fwd(const float* q, const float* k, const float* v, int64_t ld, floa
 int vd_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo, const float* dout,
                 int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldd, int32_t B,
                 int32_t nh, int32_t L, int32_t hd, float scale, void* stream);
+/* the same in two calls, for per-kernel timing: phase 1 = dQ (and delta), phase 2 = dK, dV (after phase 1) */
+int vd_attn_bwd_phase(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo, const float* dout,
+                      int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldd, int32_t B,
+                      int32_t nh, int32_t L, int32_t hd, float scale, int32_t phase, void* stream);
 
 /* layout changes at the boundary of the NCHW call surface */
 int vd_nchw_to_nhwc(const float* x, float* y, int32_t nimg, int32_t C, int32_t H, int32_t W, int64_t ldy, void* stream);

@@ -406,9 +406,10 @@ extern "C" int vd_attn_fwd(const float* q, const float* k, const float* v, int64
     return 0;
 }
 
-extern "C" int vd_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo, const float* dout,
-                           int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldd, int32_t B,
-                           int32_t nh, int32_t L, int32_t hd, float scale, void* stream) {
+namespace {
+int attn_bwd_impl(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo, const float* dout,
+                  int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldd, int32_t B,
+                  int32_t nh, int32_t L, int32_t hd, float scale, int phase, void* stream) {
     VD_REQUIRE(shape_ok(L, hd, true), "vd_attn_bwd: L=%d hd=%d not served (L %% 64 == 0, hd in {64,128})", L, hd);
     VD_REQUIRE(q && k && v && o && dout && lse && delta && dq && dk && dv && B > 0 && nh > 0, "vd_attn_bwd: null operand / empty batch");
     VD_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && ldd % 4 == 0 && vd_aligned16(q) && vd_aligned16(k) && vd_aligned16(v) &&
@@ -420,13 +421,30 @@ extern "C" int vd_attn_bwd(const float* q, const float* k, const float* v, int64
     a.lse = const_cast<float*>(lse); a.delta = delta; a.nh = nh; a.L = L; a.scale = scale;
     const dim3 grid(L / 64, B * nh);
     hipStream_t st = (hipStream_t)stream;
-    if (hd == 64) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, st, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, st, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, st, a);
+    // phase 1: dQ and delta ; phase 2: dK, dV (needs phase 1's delta) ; 0: both
+    if (phase != 2) {
+        if (hd == 64) hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, st, a);
+        VD_LAUNCH_CHECK("attn_bwd_dq_kernel");
     }
-    VD_LAUNCH_CHECK("attn_bwd kernels");
+    if (phase != 1) {
+        if (hd == 64) hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, st, a);
+        VD_LAUNCH_CHECK("attn_bwd_dkv_kernel");
+    }
     return 0;
+}
+}  // namespace
+
+extern "C" int vd_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo, const float* dout,
+                           int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldd, int32_t B,
+                           int32_t nh, int32_t L, int32_t hd, float scale, void* stream) {
+    return attn_bwd_impl(q, k, v, ld, o, ldo, dout, lddo, lse, delta, dq, dk, dv, ldd, B, nh, L, hd, scale, 0, stream);
+}
+
+extern "C" int vd_attn_bwd_phase(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo,
+                                 const float* dout, int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv,
+                                 int64_t ldd, int32_t B, int32_t nh, int32_t L, int32_t hd, float scale, int32_t phase, void* stream) {
+    VD_REQUIRE(phase == 1 || phase == 2, "vd_attn_bwd_phase: phase must be 1 (dQ, delta) or 2 (dK, dV)");
+    return attn_bwd_impl(q, k, v, ld, o, ldo, dout, lddo, lse, delta, dq, dk, dv, ldd, B, nh, L, hd, scale, phase, stream);
 }

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "vd_attn_supported": (C.c_int, [_i32, _i32, _i32]),
     "vd_attn_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "vd_attn_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "vd_attn_bwd_phase": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32,
+                                    _i32, _vp]),
     "vd_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp]),
     "vd_nhwc_to_nchw": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vd_images_to_uint8_hwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -424,11 +426,19 @@ def attn_fwd(q, k, v, ld, o, ldo, lse, B, nh, L, hd, scale):
 
 
 def attn_bwd(q, k, v, ld, o, ldo, dout, lddo, lse, delta, dq, dk, dv, ldd, B, nh, L, hd, scale):
-    """backward of attn_fwd (recomputes the probabilities); FLOPs recorded = the four products of the unfused backward
-    (8 L^2 hd per image and head) -- the kernels execute seven"""
-    with _TimedName(f"attn_bwd_kernels<{hd}>", 8.0 * B * nh * L * L * hd):
-        _check(lib().vd_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(o), ldo, ptr(dout), lddo, ptr(lse), ptr(delta), ptr(dq), ptr(dk),
-                                 ptr(dv), ldd, B, nh, L, hd, scale, stream()), "vd_attn_bwd")
+    """backward of attn_fwd (recomputes the probabilities).  FLOPs recorded are ALGORITHMIC: the four products of the backward
+    (dP, dQ to the first kernel, dV, dK to the second; 2 L^2 hd each per image and head) -- the kernels execute 3 + 4 = 7 of
+    them (the logits in both, dP again in the second), so their executed MFMA rate is 7/4 of the recorded one"""
+    args = (ptr(q), ptr(k), ptr(v), ld, ptr(o), ldo, ptr(dout), lddo, ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldd, B, nh, L, hd,
+            scale)
+    if PROFILE is None:
+        _check(lib().vd_attn_bwd(*args, stream()), "vd_attn_bwd")
+        return
+    unit = 2.0 * B * nh * L * L * hd
+    with _TimedName(f"attn_bwd_dq_kernel<{hd}>", 2 * unit):
+        _check(lib().vd_attn_bwd_phase(*args, 1, stream()), "vd_attn_bwd_phase")
+    with _TimedName(f"attn_bwd_dkv_kernel<{hd}>", 2 * unit):
+        _check(lib().vd_attn_bwd_phase(*args, 2, stream()), "vd_attn_bwd_phase")
 
 
 def nchw_to_nhwc(x, y, nimg, Cc, H, W, ldy):
