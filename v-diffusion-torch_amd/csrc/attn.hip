@@ -395,6 +395,7 @@ extern "C" int vd_attn_fwd(const float* q, const float* k, const float* v, int64
     VD_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && vd_aligned16(q) && vd_aligned16(k) && vd_aligned16(v) && vd_aligned16(o),
                "vd_attn_fwd: operands must be 16-byte aligned with row pitches that are multiples of 4 floats");
     VD_REQUIRE((long long)L * ld * 4 < (1LL << 31), "vd_attn_fwd: one image's qkv rows must stay below 2 GiB");
+    VD_REQUIRE((long long)B * nh <= 65535, "vd_attn_fwd: B * nh = %lld exceeds the grid limit 65535", (long long)B * nh);
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.ow = o; a.ldo = ldo; a.lse = lse; a.nh = nh; a.L = L; a.scale = scale;
     const dim3 grid(L / 64, B * nh);
@@ -416,6 +417,7 @@ int attn_bwd_impl(const float* q, const float* k, const float* v, int64_t ld, co
                vd_aligned16(o) && vd_aligned16(dout) && vd_aligned16(dq) && vd_aligned16(dk) && vd_aligned16(dv) && vd_aligned16(lse) &&
                vd_aligned16(delta), "vd_attn_bwd: operands must be 16-byte aligned with row pitches that are multiples of 4 floats");
     VD_REQUIRE((long long)L * ld * 4 < (1LL << 31) && (long long)L * lddo * 4 < (1LL << 31), "vd_attn_bwd: one image's rows must stay below 2 GiB");
+    VD_REQUIRE((long long)B * nh <= 65535, "vd_attn_bwd: B * nh = %lld exceeds the grid limit 65535", (long long)B * nh);
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v; a.ld = ld; a.o = o; a.ldo = ldo; a.dout = dout; a.lddo = lddo; a.dq = dq; a.dk = dk; a.dv = dv; a.ldd = ldd;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.nh = nh; a.L = L; a.scale = scale;

@@ -482,7 +482,7 @@ class UNetEngine:
         q, k, v = qkv[0, 0, 0:], qkv[0, 0, hid:], qkv[0, 0, 2 * hid:]
         O = self._new(x, B, L, hid)
         S = lse = None
-        if H.attn_supported(L, hd, tape is not None):
+        if H.attn_supported(L, hd, tape is not None) and B * nh <= 65535:
             # fused kernels (csrc/attn.hip): the [B, nh, L, L] maps never reach HBM; the backward recomputes them from the
             # per-row log-sum-exp.  (hd = 256 is served forward-only: sampling; its training step keeps the three launches.)
             if tape is not None:
