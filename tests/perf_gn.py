@@ -26,6 +26,17 @@ def case(B, R, C, film, p_drop):
     H.gn_apply(x, C, stats, gamma, beta, fl, 1, p_drop, 1234, H.RS_NONE, y, C, B, R, R, C, coef)
     dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
 
+    def fwd():
+        H.gn_apply(x, C, None, gamma, beta, fl, 1, p_drop, 1234, H.RS_NONE, y, C, B, R, R, C, coef)
+    fwd(); torch.cuda.synchronize()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record()
+    for _ in range(20):
+        fwd()
+    f1.record(); torch.cuda.synchronize()
+    tf = f0.elapsed_time(f1) / 20
+    print(f"B={B} {R}x{R} C={C} film={int(film)} p={p_drop}: apply {tf * 1e3:7.1f} us  {2 * 4.0 * B * R * R * C / tf / 1e9:6.2f} TB/s (x in, y out)   checksum {float(y.double().sum()):.6e}")
+
     def run():
         H.gn_apply_bwd(dy, C, x, C, coef, gamma, beta, fl, 1, p_drop, 1234, H.RS_NONE, None, 0, dx, C, False, dfilm, dg, db, False, B, R, R, C)
     run(); torch.cuda.synchronize()

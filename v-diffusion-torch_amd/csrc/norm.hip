@@ -199,8 +199,7 @@ struct ApplyArgs {
     int resample; float* y; long long ldy; int nimg, H, W, C;
 };
 
-__device__ __forceinline__ f32x4 fwd_one(const ApplyArgs& p, const float* ximg, int pix, int c4, f32x4 sc, f32x4 of, int b) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
+__device__ __forceinline__ f32x4 fwd_val(const ApplyArgs& p, f32x4 v, int pix, int c4, f32x4 sc, f32x4 of, int b) {
     if (p.has_norm) v = v * sc + of;
     if (p.act) {
 #pragma unroll
@@ -211,6 +210,9 @@ __device__ __forceinline__ f32x4 fwd_one(const ApplyArgs& p, const float* ximg, 
         v *= vd_dropout_scale4(p.seed, vi, p.p_drop);
     }
     return v;
+}
+__device__ __forceinline__ f32x4 fwd_one(const ApplyArgs& p, const float* ximg, int pix, int c4, f32x4 sc, f32x4 of, int b) {
+    return fwd_val(p, *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4), pix, c4, sc, of, b);
 }
 
 constexpr int APIX = 64;     // output pixels per workgroup of the apply kernels
@@ -233,11 +235,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const ApplyArgs p, int Cb
     }
     const float* ximg = p.x + (long long)b * p.H * p.W * p.ldx;
     float* yimg = p.y + (long long)b * Ho * Wo * p.ldy;
+    if (p.resample == VD_RS_NONE) {
+        // four loads in flight per thread before the first value is used (one per iteration kept the kernel at 4.3 TB/s: the loop
+        // is latency-bound, not bandwidth-bound, at 8 resident workgroups per CU)
+        for (int i = r; i < np; i += 4 * rows) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * rows < np) v[u] = *reinterpret_cast<const f32x4*>(ximg + (long long)(p0 + i + u * rows) * p.ldx + c4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * rows < np) {
+                    const int po = p0 + i + u * rows;
+                    *reinterpret_cast<f32x4*>(yimg + (long long)po * p.ldy + c4) = fwd_val(p, v[u], po, c4, sc, of, b);
+                }
+        }
+        return;
+    }
     for (int i = r; i < np; i += rows) {
         const int po = p0 + i;
         f32x4 out;
-        if (p.resample == VD_RS_NONE) out = fwd_one(p, ximg, po, c4, sc, of, b);
-        else {
+        {
             const int yo = po / Wo, xo = po - yo * Wo;
             if (p.resample == VD_RS_UP) out = fwd_one(p, ximg, (yo >> 1) * p.W + (xo >> 1), c4, sc, of, b);
             else {
