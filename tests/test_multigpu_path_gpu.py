@@ -36,3 +36,25 @@ def test_reducer_enabled_step_on_one_rank_rccl():
               open(os.path.join(ROOT, "gpurun_out", "reducer_overhead.json"), "w"))
     assert abs(forced["config"]["final_loss"] - plain["config"]["final_loss"]) < 1e-6          # a 1-rank sum is the identity
     assert b <= 1.08 * a + 1.0, f"bucketed all-reduce path costs {b - a:.2f} ms per step on one rank"
+
+
+def test_two_rank_launch_contract_on_one_gpu():
+    """The driver's N > 1 command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
+    with N = 2 ranks sharing the one GPU of the test box; the collectives travel over gloo (RCCL refuses two ranks on one
+    device), everything else is the code the 8-GPU runs execute: per-rank shards and RNG streams, bucketed gradient all-reduce
+    issued from inside backward, loss reduce, barrier + MAX-over-ranks timing, one JSON line from rank 0."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, VD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32",
+           "--no-sample", "--no-cpu-baseline", "--no-secondary", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["global_batch"] == 64 and j["config"]["parallelism"] == "dp2"
+    assert abs(j["value"] - 64 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]        # whole-job images/s = global batch / step time
+    assert 0.0 < j["config"]["final_loss"] < 10.0
