@@ -31,7 +31,7 @@ for nimg, Hh, Ww, Cin, Cout, stats in ((128, 32, 32, 256, 256, False), (128, 32,
     torch.cuda.synchronize()
     H.lib().vd_wino_set_probe(None)
     t = buf.view(nwg, 8, 8).double().cpu()
-    pro, loop, epi, wait, first, nkt = (t[..., 1] - t[..., 0]), (t[..., 2] - t[..., 1]), (t[..., 3] - t[..., 2]), t[..., 4], t[..., 5], t[..., 6]
+    pro, loop, epi, wait, nkt = (t[..., 1] - t[..., 0]), (t[..., 2] - t[..., 1]), (t[..., 3] - t[..., 2]), t[..., 4], t[..., 6]
     rt = t[..., 7]
     per = nitems / nwg
     tot = t[..., 3] - t[..., 0]
@@ -39,3 +39,6 @@ for nimg, Hh, Ww, Cin, Cout, stats in ((128, 32, 32, 256, 256, False), (128, 32,
     print(f"  cycles per wave (median): whole kernel {tot.median():.0f} = {tot.median() / per:.0f} per item = {tot.median() / per / nkt.max():.0f} per K tile "
           f"(MFMA-bound: 4096); parked at barriers {wait.median():.0f} ({100 * wait.median() / tot.median():.1f} %); prologue of the first item {pro.median():.0f}")
     print(f"  span of workgroup end times: {(rt.max() - rt.min()) / 100:.1f} us (100 MHz clock)")
+    rt0 = t[..., 5]
+    clk = (tot / (rt - rt0)).median() * 100.0                # s_memtime ticks per 100 MHz s_memrealtime tick
+    print(f"  s_memtime ticks per microsecond while this kernel runs: {clk:.0f} (MHz if s_memtime counts shader clocks); kernel {(rt.max() - rt0.min()) / 100:.1f} us")

@@ -54,6 +54,7 @@ struct WinoArgs {
     int ntiles;                                // nimg * TPI
     int ncb, ntg;                              // work items: channel blocks x tile groups
     unsigned long long* probe;                 // timing probe build only (vd_wino_set_probe): 8 x u64 per workgroup
+    int probe_light;                           // probe build: stamps at kernel start / end only (VD_WINO_PROBE_LIGHT: no per-barrier s_memtime)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
@@ -87,8 +88,8 @@ constexpr int WINO_THREADS = 768;
 // 5 = like 3 and the loaders issue no DMA (the MFMA + epilogue skeleton alone)
 template <int TW, int NS, bool STATS, bool PROBE = false, int EXP = 0>
 __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs p) {
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, tfirst = 0;
-    if (PROBE) ts0 = __builtin_amdgcn_s_memtime();
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, rt0 = 0;
+    if (PROBE) { ts0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int LGTW = TW == 4 ? 2 : (TW == 8 ? 3 : (TW == 16 ? 4 : (TW == 32 ? 5 : 6)));
     constexpr int P = TW >= 16 ? TW + 1 : (TW == 8 ? 10 : 5);      // pitch: 16 consecutive tiles read 16 distinct bank quads
     constexpr int P2 = 2 * P;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
             }
         }
         __syncthreads();                                            // [P2]
-        if (PROBE && n == 0) ts1 = __builtin_amdgcn_s_memtime();
+        if (PROBE && n == 0 && !p.probe_light) ts1 = __builtin_amdgcn_s_memtime();
 
         for (int kt = 0; kt < nkt; ++kt) {
             const int buf = (pb + kt) & 1;
@@ -329,9 +330,9 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
                     if (xi == 7) {
                         // every read of this K tile's stages is done: barrier, then the first U fragments of the next tile (or item)
                         unsigned long long tw = 0;
-                        if (PROBE) tw = __builtin_amdgcn_s_memtime();
+                        if (PROBE && !p.probe_light) tw = __builtin_amdgcn_s_memtime();
                         if (EXP != 4) __syncthreads();              // [kt]
-                        if (PROBE) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; if (kt == 0 && n == 0) tfirst = te - ts1; }
+                        if (PROBE && !p.probe_light) { const unsigned long long te = __builtin_amdgcn_s_memtime(); twait += te - tw; }
                         const float* bn = sB + (buf ^ 1) * B_STAGE + boff;
                         if (EXP != 3 && EXP != 5) {
 #pragma unroll
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tr[a][q] = trn[a][q];
         }
-        if (PROBE) ts2 = __builtin_amdgcn_s_memtime();
+        if (PROBE && !p.probe_light) ts2 = __builtin_amdgcn_s_memtime();
 
         // ---------------- epilogue: y = A^T M A (+ bias + residual)      A^T = [1 1 1 0 ; 0 1 -1 -1]
         // lane (li, lq): tile `tile`, channels co0 + 16 cb + 4 lq .. +3.  Column part in registers: s[a][v] = sum_b M[a][b] A[b][v];
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
             unsigned long long* o = p.probe + ((unsigned long long)blockIdx.x * 8 + wave) * 8;
-            o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = twait; o[5] = tfirst; o[6] = (unsigned long long)nkt;
+            o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = twait; o[5] = rt0; o[6] = (unsigned long long)nkt;
             o[7] = __builtin_amdgcn_s_memrealtime();
         }
     }
@@ -638,6 +639,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
     const dim3 grid((unsigned)(items < ncu ? items : ncu));
     hipStream_t st = (hipStream_t)stream;
     a.probe = g_probe;
+    { static const bool light = getenv("VD_WINO_PROBE_LIGHT") != nullptr; a.probe_light = light ? 1 : 0; }
     const dim3 blk(WINO_THREADS);
 #define VD_WINO_LAUNCH(TWV, NSV)                                                                                                   \
     do {                                                                                                                            \
@@ -650,11 +652,17 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
     } while (0)
     static const int exp_mode = getenv("VD_WINO_EXP") ? atoi(getenv("VD_WINO_EXP")) : 0;       // timing experiments (wrong results)
     if (exp_mode && g.TW == 16 && g.NS <= 384 && !stats_part) {
-        if (exp_mode == 1) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 1>), grid, blk, 0, st, a);
-        else if (exp_mode == 2) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 2>), grid, blk, 0, st, a);
-        else if (exp_mode == 3) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 3>), grid, blk, 0, st, a);
-        else if (exp_mode == 5) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 5>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, 4>), grid, blk, 0, st, a);
+#define VD_WINO_EXP_LAUNCH(E)                                                                                                      \
+        do {                                                                                                                        \
+            if (g_probe) hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, true, E>), grid, blk, 0, st, a);                      \
+            else hipLaunchKernelGGL((wino_conv_kernel<16, 384, false, false, E>), grid, blk, 0, st, a);                             \
+        } while (0)
+        if (exp_mode == 1) VD_WINO_EXP_LAUNCH(1);
+        else if (exp_mode == 2) VD_WINO_EXP_LAUNCH(2);
+        else if (exp_mode == 3) VD_WINO_EXP_LAUNCH(3);
+        else if (exp_mode == 5) VD_WINO_EXP_LAUNCH(5);
+        else VD_WINO_EXP_LAUNCH(4);
+#undef VD_WINO_EXP_LAUNCH
         VD_LAUNCH_CHECK("wino_conv_kernel(exp)");
         return 0;
     }
@@ -675,7 +683,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
 }
 
 /* timing probe only: device buffer of 64 u64 per workgroup (8 per wave: start, loop start, loop end, end, cycles at the tile
- * barrier, first-tile cycles, K tiles, realtime), or NULL to switch the probe off */
+ * barrier, 100 MHz realtime at start, K tiles, realtime at end), or NULL to switch the probe off */
 extern "C" int vd_wino_set_probe(unsigned long long* buf) { g_probe = buf; return 0; }
 extern "C" int vd_wino_last_kernel(void) { return g_last_wino; }
 
