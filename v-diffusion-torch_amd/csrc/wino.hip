@@ -730,6 +730,7 @@ struct WgradArgs {
     int nimg, H, W, Cin, Cout;
     int TW, TH, TPI, lgTW, lgTPI;
     int nstages, per;                  // stages in all, stages per slab
+    unsigned long long* probe;         // vd_wino_set_probe: 4 x u64 per workgroup (s_memtime / s_memrealtime at start and end), or NULL
 };
 
 // TWS = tiles of a stage per tile row = min(W/2, 16); the stage then spans NR = 16 / TWS tile rows of one image
@@ -737,6 +738,8 @@ template <int TWS, bool DBIAS>
 __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
     constexpr int NR = WG_T / TWS, P = TWS + 1, P2 = 2 * P, LG = TWS == 16 ? 4 : (TWS == 8 ? 3 : 2);
     static_assert((2 * NR + 2) * P2 <= WG_NSX, "patch image too large");
+    unsigned long long pt0 = 0, pr0 = 0;
+    if (p.probe) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WG_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -953,6 +956,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
         const int co = co0 + 32 * mh + 2 * lm;
         if (kq == 0 && co < p.Cout) *reinterpret_cast<f32x2*>(p.cpart + (long long)z * p.Cout + co) = bsum;
     }
+    if (p.probe && threadIdx.x == 0) {
+        unsigned long long* o = p.probe + 4ull * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        o[0] = pt0; o[1] = pr0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // dw[co][ci][tap] (+)= sum over the S planes (fixed order); dbias[co] (+)= sum over the S partial rows
@@ -1040,7 +1047,7 @@ static int wgrad_wino_impl(const float* xin, int64_t ldx, const float* dy, int64
     a.cpart = dbias ? ws + (size_t)g.S * 9 * Cout * Cin : nullptr;
     a.nimg = nimg; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.TW = g.TW; a.TH = g.TH; a.TPI = g.TPI; a.lgTW = ilog2(g.TW); a.lgTPI = ilog2(g.TPI);
-    a.nstages = g.nstages; a.per = g.per;
+    a.nstages = g.nstages; a.per = g.per; a.probe = g_probe;
     const dim3 grid((Cin + 63) / 64, (Cout + 63) / 64, g.S);
     hipStream_t st = (hipStream_t)stream;
 #define VD_WG_LAUNCH(T)                                                                          \
