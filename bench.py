@@ -223,6 +223,9 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
                     "note": ("Winograd F(2x2,3x3): algorithmic FLOPs = direct convolution; the kernel executes 4/9 of them on the matrix "
                              "cores (exact fp32), so frac > mfma_executed_frac and may exceed 1") if exe < 1 else None,
                     "traffic_note": f"HBM+fabric bytes per launch, PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/{tname}",
+                    "clock_note": ("peak = 2.4 GHz figure; in-kernel s_memtime/s_memrealtime stamps show the shader clock at 1.75-1.9 GHz while the "
+                                   "Winograd convolution runs and 2.1 GHz under its weight gradient (DESIGN.md section 3, tests/probe/wino_phases.py)")
+                                  if exe < 1 else None,
                     "launches_per_step": n // 2, "avg_launch_ms": round(tt_ / n * 1e3, 4),
                     "flops_per_launch": round(fl / n / 1e9, 3), "flops_unit": "GFLOP (2*M*N*K of the implicit GEMM)",
                     "share_of_matmul_time": round(tt_ / total_t, 3),
