@@ -85,7 +85,7 @@ __device__ __forceinline__ int b_swz(int row) { return (row >> 2) & 2; }
 constexpr int WINO_THREADS = 768;
 // EXP != 0: timing experiments only (WRONG results; VD_WINO_EXP, tests/probe/wino_exp.py): 1 = no input-transform arithmetic,
 // 2 = also no patch reads, 3 = also no U-fragment reads, 4 = everything but no tile barrier in the compute waves' K loop,
-// 5 = like 3 and the loaders issue no DMA (the MFMA + epilogue skeleton alone)
+// 5 = like 3 and the loaders issue no DMA (the MFMA + epilogue skeleton alone), 6 = full arithmetic but only half of the U DMA pieces
 template <int TW, int NS, bool STATS, bool PROBE = false, int EXP = 0>
 __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs p) {
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, twait = 0, rt0 = 0;
@@ -180,8 +180,10 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
                 const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.U + kt * KT);
                 float* dst = sB + buf * B_STAGE;
 #pragma unroll
-                for (int j = 0; j < BPL; ++j)
+                for (int j = 0; j < BPL; ++j) {
+                    if (EXP == 6 && (j & 1)) continue;              // timing experiment: half of the U pieces (-28 % of the staged bytes)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (LW + 4 * j) * 256), 16, (int)vb, (int)(j * xi_stride2), 0, 0);
+                }
             };
             int tbx = 0, tby = 0, nbx = 0, nby = 0;
             bool have = item_of(0, tbx, tby);
@@ -661,6 +663,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
         else if (exp_mode == 2) VD_WINO_EXP_LAUNCH(2);
         else if (exp_mode == 3) VD_WINO_EXP_LAUNCH(3);
         else if (exp_mode == 5) VD_WINO_EXP_LAUNCH(5);
+        else if (exp_mode == 6) VD_WINO_EXP_LAUNCH(6);
         else VD_WINO_EXP_LAUNCH(4);
 #undef VD_WINO_EXP_LAUNCH
         VD_LAUNCH_CHECK("wino_conv_kernel(exp)");
