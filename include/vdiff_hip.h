@@ -106,7 +106,8 @@ int vd_conv3x3_wgrad_wino_phase(const float* xin, int64_t ldx, const float* dy, 
                                 int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
                                 int32_t accumulate, float* ws, size_t ws_bytes, int32_t phase, void* stream);
 /* (TW * 1000 + NS) * 2 + stats of the calling thread's last vd_conv3x3_wino launch: names the instantiation
- * wino_conv_kernel<TW, NS, stats, false, 0> (profiling aid, like vd_gemm_last_tile) */
+ * wino_conv_kernel<TW, NS, stats, false, 0>; negated when the launch took the 128-tile form wino_conv_wide_kernel<TW, NS, stats>
+ * (profiling aid, like vd_gemm_last_tile) */
 int vd_wino_last_kernel(void);
 /* diagnostics: per-wave phase timestamps of the next vd_conv3x3_wino launches into buf (64 x uint64 per workgroup), NULL = off */
 int vd_wino_set_probe(unsigned long long* buf);

@@ -461,6 +461,245 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
     }
 }
 
+// ---- the same convolution with work items of 128 tiles x 32 channels ("wide" form).
+// Why a second form: these kernels are clock-limited -- what they pay for is bytes and instructions per MFMA,
+// not stalls.  A 128-tile item shares one U stage between twice as many tiles (-36 % staged bytes per MFMA; a timing build of the
+// kernel above with half of its U pieces gained 4 % of clock at the same cycle count), every wave owns ALL 16 xi of its 16 tiles (each
+// patch position is read and row-transformed once instead of by two waves: -33 % patch reads and transform instructions, and the
+// output transform is lane-local: no exchange through LDS), at the price of 128 accumulator registers per wave: 8 waves of 256
+// registers, no loader waves -- every wave issues a ninth of the next K tile's DMA between its MFMA steps.
+// Stage protocol: patch and U of K tile g (a counter that runs on across the items of a workgroup) live in stage g & 1; the DMA of
+// g + 1 is issued during g; one barrier per K tile.  The epilogue touches no LDS, so the first K tile of the next item streams in
+// behind it.
+constexpr int TILES_WIDE = 128;
+constexpr int WIDE_THREADS = 512;
+
+// bias + residual, dwordx4 stores of a tile's 2x2 output pixels, optional GroupNorm partial sums (lanes: li = tile of the 16-tile
+// group, lq = channel quad)
+template <int TW, bool STATS>
+__device__ __forceinline__ void wino_store_outputs(const WinoArgs& p, const f32x4 (&F)[2][2], int group_tile0, int li, int co) {
+    constexpr int LGTW = TW == 4 ? 2 : (TW == 8 ? 3 : (TW == 16 ? 4 : (TW == 32 ? 5 : 6)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int tile = group_tile0 + li;
+    const int tin = tile & (p.TPI - 1);
+    const int ty = tin >> LGTW, tx = tin & (TW - 1);
+    const int img = tile >> p.lgTPI;
+    const long long pix00 = ((long long)img * p.H + 2 * ty) * p.W + 2 * tx;
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
+    const bool ok = tile < p.ntiles && co < p.Cout;                 // (Cout is a multiple of 4)
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ok) b4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    f32x4 r4[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const unsigned vor = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldr + co) * 4) : OOB;
+            r4[u][v] = p.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const f32x4 val = (F[u][v] + b4) + r4[u][v];
+            if (STATS) { a1 += val; a2 += val * val; }
+            const unsigned voc = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldy + co) * 4) : OOB;
+            const u32x4 wv = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(wv, yrs, (int)voc, 0, 0);
+        }
+    if (STATS) {
+        // sum over the group's 16 tiles (= lanes with equal lq): fixed-order butterfly, then lane li = 0 writes its 4 channels of
+        // the [2][Cout] record of the tile group's 64-pixel chunk (all 16 tiles lie in one image)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v1 = a1[j], v2 = a2[j];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 16); v2 += __shfl_xor(v2, o, 16); }
+            a1[j] = v1; a2[j] = v2;
+        }
+        if (li == 0 && group_tile0 < p.ntiles && co < p.Cout) {
+            const int wimg = group_tile0 >> p.lgTPI, chunk = (group_tile0 & (p.TPI - 1)) >> 4;
+            float* o = p.stats + ((long long)wimg * (p.TPI >> 4) + chunk) * 2 * p.Cout;
+            *reinterpret_cast<f32x4*>(o + co) = a1;
+            *reinterpret_cast<f32x4*>(o + p.Cout + co) = a2;
+        }
+    }
+}
+
+template <int TW, int NS, bool STATS>
+__global__ __launch_bounds__(WIDE_THREADS) void wino_conv_wide_kernel(const WinoArgs p) {
+    constexpr int LGTW = TW == 8 ? 3 : (TW == 16 ? 4 : 5);
+    constexpr int P = TW >= 16 ? TW + 1 : 10;
+    constexpr int P2 = 2 * P;
+    constexpr int A_STAGE = 4 * NS * 4;                 // floats
+    constexpr int SG = NS / 64;                         // slot groups (DMA pieces) per 16-byte channel chunk
+    constexpr int APL = 4 * SG / 8;                     // patch pieces per wave and stage
+    static_assert((4 * SG) % 8 == 0, "every wave issues the same number of patch pieces");
+    static_assert((2 * A_STAGE + 2 * B_STAGE) * 4 <= 163840, "stages exceed the LDS");
+    __shared__ __attribute__((aligned(1024))) float smem[2 * A_STAGE + 2 * B_STAGE];
+    float* const sA = smem;
+    float* const sB = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int nkt = p.K / KT;
+    const int G = gridDim.x, w = blockIdx.x;
+    const int nitems = p.ncb * p.ntg;
+    auto item_of = [&](int n, int& tbx, int& tby) -> bool {
+        int t = n * G + w;
+        if ((G & 7) == 0 && (n + 1) * G <= nitems) t = n * G + (w & 7) * (G >> 3) + (w >> 3);
+        if (t >= nitems) return false;
+        if ((p.ncb & 3) == 0 && p.ncb > 4 && (p.ntg & 7) == 0) {
+            const int c = t >> 5, i = t & 31, ncg = p.ncb >> 2;
+            tbx = (c % ncg) * 4 + (i & 3); tby = (c / ncg) * 8 + (i >> 2);
+            return true;
+        }
+        tbx = t % p.ncb; tby = t / p.ncb;
+        return true;
+    };
+
+    // ---- DMA: wave w issues patch pieces q = w + 8 j (chunk q / SG by scalar offset, slot group q % SG per lane) and U pieces w + 8 j
+    // (16-channel half w & 1, xi = (w >> 1) + 4 j by scalar offset)
+    unsigned pxo[APL], vb0 = 0;
+    const unsigned xi_stride4 = 4u * (unsigned)p.Cout * (unsigned)p.K * 4u;
+    auto offsets = [&](int tbx, int tby) {
+        const int co0 = tbx * TN;
+        const int tile0 = tby * TILES_WIDE;
+        const int img0 = tile0 >> p.lgTPI;
+        const int trow0 = (tile0 & (p.TPI - 1)) >> LGTW;
+        const int y_first = 2 * trow0 - 1;
+#pragma unroll
+        for (int j = 0; j < APL; ++j) {
+            const int g = (wave + 8 * j) % SG;
+            const int s = g * 64 + lane;
+            const int rr = s / P2, rem = s - rr * P2;
+            const int par = rem >= P ? 1 : 0, idx = rem - par * P;
+            int il = (int)((float)rr * p.invRIN);
+            if (il * p.RIN > rr) --il; else if ((il + 1) * p.RIN <= rr) ++il;
+            const int r = rr - il * p.RIN;
+            const int yy = y_first + r, xx = 2 * idx - 1 + par;
+            const int img = img0 + il;
+            unsigned vo = OOB;
+            if (il < p.NIW && img < p.nimg && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                vo = (unsigned)((((long long)img * p.H + yy) * p.W + xx) * p.ldx) * 4u;
+            pxo[j] = vo;
+        }
+        const int row = lane >> 2, c = (lane & 3) ^ b_swz(row);
+        const int co = co0 + (wave & 1) * 16 + row;
+        vb0 = co < p.Cout ? (unsigned)((((long long)(wave >> 1) * p.Cout + co) * p.K + c * 4) * 4) : OOB;
+    };
+    // piece i of the 4 U + APL patch pieces this wave owes to K tile kt (stage st)
+    auto issue_piece = [&](int i, int kt, int st) {
+        if (i < 4) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.U + kt * KT);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sB + st * B_STAGE + (wave + 8 * i) * 256), 16, (int)vb0, (int)(i * xi_stride4), 0, 0);
+        } else {
+            const int j = i - 4, q = wave + 8 * j;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sA + st * A_STAGE + q * 256), 16, (int)pxo[j], (q / SG) * 16, 0, 0);
+        }
+    };
+    constexpr int NPIECE = 4 + APL;
+
+    auto poff = [](int q) { return ((q & 1) * P + (q >> 1)) * 4; };
+    const int boff = li * KT + ((lq ^ b_swz(li)) << 2);
+
+    int tbx = 0, tby = 0, nbx = 0, nby = 0;
+    bool have = item_of(0, tbx, tby);
+    int gk = 0;                                                     // K tiles done by this workgroup (stage parity)
+    if (have) {
+        offsets(tbx, tby);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) issue_piece(i, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int n = 0; have; ++n) {
+        const int co0 = tbx * TN;
+        const int tile0 = tby * TILES_WIDE;
+        const int trow0 = (tile0 & (p.TPI - 1)) >> LGTW;
+        const int tl = 16 * wave + li;
+        const int tile = tile0 + tl;
+        const int il = tl >> p.lgTPI;
+        const int tin = (tile & (p.TPI - 1));
+        const int ty = tin >> LGTW, tx = tin & (TW - 1);
+        const int slot0 = ((il * p.RIN + 2 * (ty - trow0)) * 2) * P + tx;
+        const float* pbase = sA + (lq * NS + slot0) * 4;
+        const bool next = item_of(n + 1, nbx, nby);
+
+        f32x4 acc[16][2];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[xi][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nkt; ++kt, ++gk) {
+            const int st = gk & 1;
+            const bool last = kt == nkt - 1;
+            if (last && next) offsets(nbx, nby);                    // (this item's DMA is all issued: the registers are free)
+            const bool dma = !last || next;
+            const int nkt_i = last ? 0 : kt + 1;
+            const float* pa = pbase + st * A_STAGE;
+            const float* bs = sB + st * B_STAGE + boff;
+            f32x4 d[4][4];
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[pr][q] = *reinterpret_cast<const f32x4*>(pa + pr * P2 * 4 + poff(q));
+            f32x4 ub[2][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) ub[0][cb] = *reinterpret_cast<const f32x4*>(bs + cb * 256);
+            // rows: tr[0] = d0 - d2, tr[1] = d1 + d2, tr[2] = d2 - d1, tr[3] = d1 - d3   (in place)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 d0 = d[0][q], d1 = d[1][q], d2 = d[2][q], d3 = d[3][q];
+                d[0][q] = d0 - d2; d[1][q] = d1 + d2; d[2][q] = d2 - d1; d[3][q] = d1 - d3;
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                const int a = xi >> 2, b = xi & 3;
+                if (xi < 15) {
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) ub[(xi + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 1) * 2 + cb) * 256);
+                }
+                if (dma && xi < NPIECE) issue_piece(xi, nkt_i, st ^ 1);
+                const f32x4 V = b == 0 ? d[a][0] - d[a][2] : (b == 1 ? d[a][1] + d[a][2] : (b == 2 ? d[a][2] - d[a][1] : d[a][1] - d[a][3]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi & 1][0][j], V[j], acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi & 1][1][j], V[j], acc[xi][1], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+
+        // ---------------- epilogue: y = A^T M A (+ bias + residual), all 16 xi in the lane      A^T = [1 1 1 0 ; 0 1 -1 -1]
+        int tby_e = tby, lane_e = lane;
+        asm volatile("" : "+s"(tby_e));
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 15, lq_e = lane_e >> 4;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 s0[4], s1[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 t1 = acc[4 * a + 1][cb] + acc[4 * a + 2][cb], t2 = acc[4 * a + 1][cb] - acc[4 * a + 2][cb];
+                s0[a] = acc[4 * a][cb] + t1;
+                s1[a] = t2 - acc[4 * a + 3][cb];
+            }
+            f32x4 F[2][2];
+            F[0][0] = s0[0] + s0[1] + s0[2]; F[0][1] = s1[0] + s1[1] + s1[2];
+            F[1][0] = s0[1] - s0[2] - s0[3]; F[1][1] = s1[1] - s1[2] - s1[3];
+            wino_store_outputs<TW, STATS>(p, F, tby_e * TILES_WIDE + 16 * wave, li_e, co0 + 16 * cb + 4 * lq_e);
+        }
+        have = next; tbx = nbx; tby = nby;
+    }
+}
+
 // ---- weight transform: uf[xi][co][ci] = (G w[co][ci] G^T)[xi] ; ud[xi][ci][co] = (G rot180(w[co][ci]) G^T)[xi]
 // G = [1 0 0 ; .5 .5 .5 ; .5 -.5 .5 ; 0 0 1]
 __device__ __forceinline__ void g_transform(const float (&w)[3][3], float (&u)[4][4]) {
@@ -599,6 +838,22 @@ Plan plan_of(int H, int W) {
     return g;
 }
 
+// geometry of the wide form (128 tiles per item): TW in {8, 16, 32} with at most 768 patch slots per chunk
+Plan plan_wide(int H, int W) {
+    Plan g = {};
+    if (H % 2 || W % 2) return g;
+    g.TW = W / 2; g.TH = H / 2; g.TPI = g.TW * g.TH;
+    if (!pow2(g.TW) || !pow2(g.TH) || (g.TW != 8 && g.TW != 16 && g.TW != 32) || g.TPI < 16) return g;
+    if (g.TPI >= TILES_WIDE) { g.nwgimg = 1; g.NTR = TILES_WIDE / g.TW; if (g.NTR < 1 || g.NTR > g.TH) return g; }
+    else { g.nwgimg = TILES_WIDE / g.TPI; g.NTR = g.TH; }
+    g.RIN = 2 * g.NTR + 2;
+    g.P = g.TW >= 16 ? g.TW + 1 : 10;
+    const int slots = g.nwgimg * g.RIN * 2 * g.P;
+    g.NS = (slots + 127) / 128 * 128;
+    g.ok = g.NS <= 768;
+    return g;
+}
+
 }  // namespace
 
 extern "C" int vd_conv3x3_wino_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t ldy,
@@ -620,6 +875,52 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
                "vd_conv3x3_wino: unsupported geometry nimg=%d H=%d W=%d Cin=%d Cout=%d (use vd_conv3x3)", nimg, H, W, Cin, Cout);
     VD_REQUIRE(vd_aligned16(xin) && vd_aligned16(U) && vd_aligned16(y) && (!res || vd_aligned16(res)) && (!bias || vd_aligned16(bias)),
                "vd_conv3x3_wino: operands must be 16-byte aligned");
+    static int ncu = 0;                       // persistent workgroups: one per CU (the LDS footprint admits no second one)
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu = prop.multiProcessorCount;
+        else ncu = 256;
+    }
+    {
+        // wide form (128-tile items, ~5 % faster per unit of work: same-box A/B in tests/perf_wino.py) wherever its items fill the
+        // residency rounds at least as well as the 64-tile items do: rounds x 2 x 0.95 against the narrow form's rounds
+        // (576 -> 576 @16x16, 4.5 rounds of wide items, measured 6 % slower than 9 full narrow rounds).  VD_WINO_WIDE=0 / 1 forces.
+        static const int wide_env = getenv("VD_WINO_WIDE") ? atoi(getenv("VD_WINO_WIDE")) : -1;
+        const Plan gw = plan_wide(H, W);
+        const long long ntiles = (long long)nimg * gw.TPI;
+        const long long ncbw = (Cout + TN - 1) / TN;
+        const long long witems = gw.ok ? ncbw * ((ntiles + TILES_WIDE - 1) / TILES_WIDE) : 0;
+        const long long nitems = ncbw * ((ntiles + TILES_WG - 1) / TILES_WG);
+        const long long wrounds = (witems + ncu - 1) / ncu, nrounds = (nitems + ncu - 1) / ncu;
+        const bool wide = wide_env >= 0 ? wide_env != 0 : (witems >= ncu && 1.9 * (double)wrounds <= (double)nrounds);
+        if (wide && gw.ok && !g_probe) {
+            WinoArgs a = {};
+            a.x = xin; a.ldx = ldx; a.U = U; a.bias = bias; a.res = res; a.ldr = ldres; a.y = y; a.ldy = ldy; a.stats = stats_part;
+            a.nimg = nimg; a.H = H; a.W = W; a.K = Cin; a.Cout = Cout;
+            a.TW = gw.TW; a.TH = gw.TH; a.TPI = gw.TPI; a.P = gw.P; a.RIN = gw.RIN; a.NTR = gw.NTR; a.NIW = gw.nwgimg;
+            a.lgTW = ilog2(gw.TW); a.lgTPI = ilog2(gw.TPI); a.ntiles = (int)ntiles;
+            a.invP2 = 1.0f / (float)(2 * gw.P); a.invRIN = 1.0f / (float)gw.RIN;
+            a.ncb = (Cout + TN - 1) / TN; a.ntg = (int)((ntiles + TILES_WIDE - 1) / TILES_WIDE);
+            const dim3 grid((unsigned)(witems < ncu ? witems : ncu)), blk(WIDE_THREADS);
+            hipStream_t st = (hipStream_t)stream;
+#define VD_WIDE_LAUNCH(TWV, NSV)                                                                                                   \
+            do {                                                                                                                    \
+                g_last_wino = -(((TWV) * 1000 + (NSV)) * 2 + (stats_part ? 1 : 0));      /* negative: the wide form */              \
+                if (stats_part) hipLaunchKernelGGL((wino_conv_wide_kernel<TWV, NSV, true>), grid, blk, 0, st, a);                    \
+                else hipLaunchKernelGGL((wino_conv_wide_kernel<TWV, NSV, false>), grid, blk, 0, st, a);                              \
+            } while (0)
+            if (gw.TW == 16 && gw.NS <= 640) VD_WIDE_LAUNCH(16, 640);
+            else if (gw.TW == 16) VD_WIDE_LAUNCH(16, 768);
+            else if (gw.TW == 8) VD_WIDE_LAUNCH(8, 768);
+            else VD_WIDE_LAUNCH(32, 768);
+#undef VD_WIDE_LAUNCH
+            VD_LAUNCH_CHECK("wino_conv_wide_kernel");
+            vd_g_last_tile = ((16 * 1000) + 128) * 1000 + TN;
+            return 0;
+        }
+    }
     const Plan g = plan_of(H, W);
     WinoArgs a = {};
     a.x = xin; a.ldx = ldx; a.U = U; a.bias = bias; a.res = res; a.ldr = ldres; a.y = y; a.ldy = ldy; a.stats = stats_part;
@@ -630,14 +931,6 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
     a.ncb = (Cout + TN - 1) / TN; a.ntg = (a.ntiles + TILES_WG - 1) / TILES_WG;
     const long long items = (long long)a.ncb * a.ntg;
     VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_wino: too many work items");
-    static int ncu = 0;                       // persistent workgroups: one per CU (the LDS footprint admits no second one)
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
-        else ncu = 256;
-    }
     const dim3 grid((unsigned)(items < ncu ? items : ncu));
     hipStream_t st = (hipStream_t)stream;
     a.probe = g_probe;

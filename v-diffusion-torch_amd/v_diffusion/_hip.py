@@ -259,7 +259,11 @@ def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres
                                      ptr(stats_part), stream()), "vd_conv3x3_wino")
         if PROFILE is not None:
             k = lib().vd_wino_last_kernel()
-            t.name = t.name.format(tw=k // 2000, ns=(k // 2) % 1000, st="true" if k & 1 else "false")
+            if k < 0:                       # the 128-tile ("wide") form
+                k = -k
+                t.name = f"wino_conv_wide_kernel<{k // 2000}, {(k // 2) % 1000}, {'true' if k & 1 else 'false'}>"
+            else:
+                t.name = t.name.format(tw=k // 2000, ns=(k // 2) % 1000, st="true" if k & 1 else "false")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):
