@@ -19,8 +19,9 @@ for nimg, Hh, Ww, Cin, Cout, stats in ((128, 32, 32, 256, 256, False), (128, 32,
     res = torch.randn_like(y)
     b = torch.randn(Cout, device=DEV)
     part = torch.empty(H.stats_part_numel(nimg, Hh * Ww, Cout), device=DEV)
-    nwg = min(256, (Cout // 32) * (nimg * Hh * Ww // 4 // 64))      # persistent workgroups: one per CU
-    nitems = (Cout // 32) * (nimg * Hh * Ww // 4 // 64)
+    TPW = 64 if os.environ.get("VD_WINO_WIDE") == "0" or Hh < 16 else 128     # tiles per item (the wide form serves 16x16 and larger)
+    nwg = min(256, (Cout // 32) * (nimg * Hh * Ww // 4 // TPW))      # persistent workgroups: one per CU
+    nitems = (Cout // 32) * (nimg * Hh * Ww // 4 // TPW)
     buf = torch.zeros(nwg * 64, dtype=torch.int64, device=DEV)
     for _ in range(3):
         H.conv3x3_wino(x, Cin, uf, b if stats else None, y, Cout, nimg, Hh, Ww, Cin, Cout, res=res if stats else None, ldres=Cout,
@@ -37,7 +38,7 @@ for nimg, Hh, Ww, Cin, Cout, stats in ((128, 32, 32, 256, 256, False), (128, 32,
     tot = t[..., 3] - t[..., 0]
     print(f"{nimg}x{Hh}x{Ww} {Cin}->{Cout} stats={stats}: workgroups {nwg} x {per:.0f} items, K tiles per item {int(nkt.max())}")
     print(f"  cycles per wave (median): whole kernel {tot.median():.0f} = {tot.median() / per:.0f} per item = {tot.median() / per / nkt.max():.0f} per K tile "
-          f"(MFMA-bound: 4096); parked at barriers {wait.median():.0f} ({100 * wait.median() / tot.median():.1f} %); prologue of the first item {pro.median():.0f}")
+          f"(MFMA-bound: {4096 * TPW // 64}); parked at barriers {wait.median():.0f} ({100 * wait.median() / tot.median():.1f} %); prologue of the first item {pro.median():.0f}")
     print(f"  span of workgroup end times: {(rt.max() - rt.min()) / 100:.1f} us (100 MHz clock)")
     rt0 = t[..., 5]
     clk = (tot / (rt - rt0)).median() * 100.0                # s_memtime ticks per 100 MHz s_memrealtime tick

@@ -8,6 +8,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 void vd_set_error(const char* fmt, ...);
 extern thread_local int vd_g_last_tile;      // code of the calling thread's last matmul-shaped launch (vd_gemm_last_tile)
 

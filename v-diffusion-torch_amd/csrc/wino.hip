@@ -548,6 +548,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void wino_conv_wide_kernel(const Wino
     const int nkt = p.K / KT;
     const int G = gridDim.x, w = blockIdx.x;
     const int nitems = p.ncb * p.ntg;
+    unsigned long long pt0 = 0, pr0 = 0;                            // vd_wino_set_probe: clock stamps at kernel start / end
+    if (p.probe) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     auto item_of = [&](int n, int& tbx, int& tby) -> bool {
         int t = n * G + w;
         if ((G & 7) == 0 && (n + 1) * G <= nitems) t = n * G + (w & 7) * (G >> 3) + (w >> 3);
@@ -644,29 +646,48 @@ __global__ __launch_bounds__(WIDE_THREADS) void wino_conv_wide_kernel(const Wino
             const int nkt_i = last ? 0 : kt + 1;
             const float* pa = pbase + st * A_STAGE;
             const float* bs = sB + st * B_STAGE + boff;
+            // Patch rows 0 and 2 first: tr[0] = d0 - d2 is all the first four steps need; rows 1 and 3 arrive behind their MFMAs and
+            // become tr[1] = d1 + d2 (into d[0]), tr[2] = d2 - d1 (into d[2]), tr[3] = d1 - d3 (into d[1]) between steps 3 and 4.
+            // V of step xi + 1 is formed BEFORE the MFMAs of step xi (gfx90a+ wants two wait states between a VALU write and the MFMA
+            // that reads it).  (Tried: v_pk_add_f32 with the negate modifier through inline asm -- hipcc scalarises float4 subtractions
+            // into four v_sub_f32 -- gains 4 % only as long as it skips those wait states, i.e. only while it computes garbage.)
             f32x4 d[4][4];
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) d[pr][q] = *reinterpret_cast<const f32x4*>(pa + pr * P2 * 4 + poff(q));
+            for (int q = 0; q < 4; ++q) {
+                d[0][q] = *reinterpret_cast<const f32x4*>(pa + 0 * P2 * 4 + poff(q));
+                d[2][q] = *reinterpret_cast<const f32x4*>(pa + 2 * P2 * 4 + poff(q));
+            }
             f32x4 ub[2][2];
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) ub[0][cb] = *reinterpret_cast<const f32x4*>(bs + cb * 256);
-            // rows: tr[0] = d0 - d2, tr[1] = d1 + d2, tr[2] = d2 - d1, tr[3] = d1 - d3   (in place)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 d0 = d[0][q], d1 = d[1][q], d2 = d[2][q], d3 = d[3][q];
-                d[0][q] = d0 - d2; d[1][q] = d1 + d2; d[2][q] = d2 - d1; d[3][q] = d1 - d3;
+                d[1][q] = *reinterpret_cast<const f32x4*>(pa + 1 * P2 * 4 + poff(q));
+                d[3][q] = *reinterpret_cast<const f32x4*>(pa + 3 * P2 * 4 + poff(q));
             }
 #pragma unroll
+            for (int q = 0; q < 4; ++q) d[0][q] -= d[2][q];
+            auto vof = [&](int xi) -> f32x4 {                       // V[a][b] from the physical row that holds tr[a]
+                const int a = xi >> 2, b = xi & 3, r = a == 0 ? 0 : (a == 1 ? 0 : (a == 2 ? 2 : 1));
+                return b == 0 ? d[r][0] - d[r][2] : (b == 1 ? d[r][1] + d[r][2] : (b == 2 ? d[r][2] - d[r][1] : d[r][1] - d[r][3]));
+            };
+            f32x4 Vn = vof(0);
+#pragma unroll
             for (int xi = 0; xi < 16; ++xi) {
-                const int a = xi >> 2, b = xi & 3;
+                const f32x4 V = Vn;
                 if (xi < 15) {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) ub[(xi + 1) & 1][cb] = *reinterpret_cast<const f32x4*>(bs + ((xi + 1) * 2 + cb) * 256);
                 }
                 if (dma && xi < NPIECE) issue_piece(xi, nkt_i, st ^ 1);
-                const f32x4 V = b == 0 ? d[a][0] - d[a][2] : (b == 1 ? d[a][1] + d[a][2] : (b == 2 ? d[a][2] - d[a][1] : d[a][1] - d[a][3]));
+                if (xi == 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 d1 = d[1][q], d2 = d[2][q];
+                        d[0][q] = d1 + d2; d[2][q] = d2 - d1; d[1][q] = d1 - d[3][q];
+                    }
+                }
+                if (xi < 15) Vn = vof(xi + 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi & 1][0][j], V[j], acc[xi][0], 0, 0, 0);
@@ -697,6 +718,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void wino_conv_wide_kernel(const Wino
             wino_store_outputs<TW, STATS>(p, F, tby_e * TILES_WIDE + 16 * wave, li_e, co0 + 16 * cb + 4 * lq_e);
         }
         have = next; tbx = nbx; tby = nby;
+    }
+    if (p.probe && lane == 0) {
+        // same record as the narrow kernel's probe (8 x u64 per wave): start, -, -, end, -, realtime at start, K tiles, realtime at end
+        unsigned long long* o = p.probe + ((unsigned long long)blockIdx.x * 8 + wave) * 8;
+        o[0] = pt0; o[1] = pt0; o[2] = pt0; o[3] = __builtin_amdgcn_s_memtime(); o[4] = 0; o[5] = pr0; o[6] = (unsigned long long)nkt;
+        o[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -895,7 +922,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
         const long long nitems = ncbw * ((ntiles + TILES_WG - 1) / TILES_WG);
         const long long wrounds = (witems + ncu - 1) / ncu, nrounds = (nitems + ncu - 1) / ncu;
         const bool wide = wide_env >= 0 ? wide_env != 0 : (witems >= ncu && 1.9 * (double)wrounds <= (double)nrounds);
-        if (wide && gw.ok && !g_probe) {
+        if (wide && gw.ok) {
             WinoArgs a = {};
             a.x = xin; a.ldx = ldx; a.U = U; a.bias = bias; a.res = res; a.ldr = ldres; a.y = y; a.ldy = ldy; a.stats = stats_part;
             a.nimg = nimg; a.H = H; a.W = W; a.K = Cin; a.Cout = Cout;
@@ -903,6 +930,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
             a.lgTW = ilog2(gw.TW); a.lgTPI = ilog2(gw.TPI); a.ntiles = (int)ntiles;
             a.invP2 = 1.0f / (float)(2 * gw.P); a.invRIN = 1.0f / (float)gw.RIN;
             a.ncb = (Cout + TN - 1) / TN; a.ntg = (int)((ntiles + TILES_WIDE - 1) / TILES_WIDE);
+            a.probe = g_probe;
             const dim3 grid((unsigned)(witems < ncu ? witems : ncu)), blk(WIDE_THREADS);
             hipStream_t st = (hipStream_t)stream;
 #define VD_WIDE_LAUNCH(TWV, NSV)                                                                                                   \
@@ -1113,7 +1141,6 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
     // ---------------- LDS reads.  K step ks feeds tile t = 4 ks + kq of the stage to lane group kq.
     // dY slot = (2u+v) * 16 + t;  patch slot of position (pr, q) of this xi half = ((2 dty + ah + pr) * 2 + (q & 1)) * P + dtx + (q >> 1).
     // Lane part (kq, halves, channel pair) in two base registers per operand, the rest is an immediate offset.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int dbase = kq * 256 + ((mh ^ (kq & 1)) << 7) + lm * 8;
     const int xb_even = WG_DY_BYTES + (kq + ah * P2) * 256 + ((nh ^ (kq & 1)) << 7) + lm * 8;
     const int xb_odd = WG_DY_BYTES + (kq + ah * P2) * 256 + ((nh ^ (kq & 1) ^ 1) << 7) + lm * 8;
