@@ -751,6 +751,25 @@ def test_kernel_variants_in_subprocess(H, knobs):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_wino_forms_in_subprocess(H, wide):
+    """The launcher picks between the 64-tile and the 128-tile ("wide") form of the Winograd convolution by how the items fill
+    the residency rounds, so a plain run sends the small parity cases to the 64-tile form and the benchmark shapes to the wide
+    one.  VD_WINO_WIDE forces one form for every geometry it serves: the ragged / multi-image / partial-channel-block cases
+    through the wide kernel (1), the benchmark shapes through the 64-tile kernel (0)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VD_WINO_WIDE=wide)
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = [os.path.join(here, "test_kernels_gpu.py")] + ([os.path.join(here, "test_bench_shapes_gpu.py")] if wide == "0" else [])
+    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-q", "-x", "--no-header", "-p", "no:cacheprovider", "-k",
+                        "conv3x3_wino_forward_stats_dgrad or conv3x3_stats_at_bench_shapes or conv3x3_dgrad_at_bench_shape"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) convolution
 WINO_CASES = [  # nimg, H, W, Cin, Cout, ldx_extra, ldy_extra      (geometries: every patch-image variant of csrc/wino.hip)
     (2, 32, 32, 64, 64, 0, 0),       # 16 tiles per row: one workgroup = 4 tile rows of one image
