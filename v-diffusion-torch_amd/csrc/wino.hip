@@ -1192,24 +1192,28 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { tr[0][q] = L[1][q] - L[0][q]; tr[1][q] = L[0][q] - L[2][q]; }
         }
+        // all 16 operands first, then the 32 MFMAs: a VALU result consumed by the very next MFMA costs wait states
+        f32x2 A4[2][4], V[2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            f32x2 A4[4], V[4];
 #if defined(VD_WGRAD_EXP) && VD_WGRAD_EXP >= 3
-            A4[0] = m[a][0]; A4[1] = m[a][1]; A4[2] = m[a][0]; A4[3] = m[a][1];
-            V[0] = tr[a][0]; V[1] = tr[a][1]; V[2] = tr[a][2]; V[3] = tr[a][3];
+            A4[a][0] = m[a][0]; A4[a][1] = m[a][1]; A4[a][2] = m[a][0]; A4[a][3] = m[a][1];
+            V[a][0] = tr[a][0]; V[a][1] = tr[a][1]; V[a][2] = tr[a][2]; V[a][3] = tr[a][3];
 #else
-            A4[0] = m[a][0]; A4[1] = m[a][0] + m[a][1]; A4[2] = m[a][0] - m[a][1]; A4[3] = m[a][1];
-            V[0] = tr[a][0] - tr[a][2]; V[1] = tr[a][1] + tr[a][2]; V[2] = tr[a][2] - tr[a][1]; V[3] = tr[a][1] - tr[a][3];
+            A4[a][0] = m[a][0]; A4[a][1] = m[a][0] + m[a][1]; A4[a][2] = m[a][0] - m[a][1]; A4[a][3] = m[a][1];
+            V[a][0] = tr[a][0] - tr[a][2]; V[a][1] = tr[a][1] + tr[a][2]; V[a][2] = tr[a][2] - tr[a][1]; V[a][3] = tr[a][1] - tr[a][3];
 #endif
+        }
+        __builtin_amdgcn_sched_barrier(0x0180 | 0x0004 | 0x0010 | 0x0020 | 0x0040 | 0x0200);     // (VALU and MFMA stay on their sides)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
-                        acc[4 * a + b][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[b][mb], V[b][nb], acc[4 * a + b][mb][nb], 0, 0, 0);
-        }
+                        acc[4 * a + b][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[a][b][mb], V[a][b][nb], acc[4 * a + b][mb][nb], 0, 0, 0);
     };
 
     if (st_begin < st_end) {
