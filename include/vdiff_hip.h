@@ -109,8 +109,15 @@ int vd_conv3x3_wgrad_wino_phase(const float* xin, int64_t ldx, const float* dy, 
  * wino_conv_kernel<TW, NS, stats, false, 0>; negated when the launch took the 128-tile form wino_conv_wide_kernel<TW, NS, stats>
  * (profiling aid, like vd_gemm_last_tile) */
 int vd_wino_last_kernel(void);
-/* diagnostics: per-wave phase timestamps of the next vd_conv3x3_wino launches into buf (64 x uint64 per workgroup), NULL = off */
+/* (TWS * 1000 + split-K slabs) * 2 + dbias of the calling thread's last vd_conv3x3_wgrad_wino launch: names the instantiation
+ * wino_wgrad_kernel<TWS, dbias> (TWS = min(W/2, 16)) and its slab count (profiling / test aid) */
+int vd_wino_wgrad_last_kernel(void);
+#ifdef VD_PROBES
+/* libvdiff_hip_probe.so only (built with -DVD_PROBES for tests/probe/; the product library has no timing-probe or timing-experiment
+ * code): per-wave phase timestamps of the next vd_conv3x3_wino / vd_conv3x3_wgrad_wino launches into buf (64 x uint64 per
+ * workgroup), NULL = off */
 int vd_wino_set_probe(unsigned long long* buf);
+#endif
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
 /* all 3x3 kernels of a network in one launch: items_dev = [n][8] int64 {w, uf, ud, Cout, Cin, tiled, 0, first 256-thread block};
  * tiled = 1 (Cout, Cin multiples of 16): the tensor takes (Cout/16)*(Cin/16) blocks of one 16x16 tile, else ceil(Cout*Cin/256) */
@@ -285,9 +292,14 @@ int vd_sample_step(const float* xt, const float* out, const float* noise, const 
  * sum of squares of a flat buffer (global-norm clip), fused clip + AdamW + EMA over flat fp32 buffers */
 size_t vd_sumsq_ws_bytes(int64_t n);
 int vd_sumsq(const float* g, int64_t n, float* out1, float* ws, size_t ws_bytes, void* stream);
+/* [r_lo, r_hi) with r_mode != 0 is an index range treated apart this step (the class-embedding tensors, unet.py:207-215):
+ * r_mode 1 = the range received no gradient (class-conditional net called with y = None; the reference leaves .grad None and
+ * torch.optim.AdamW skips it: p, m, v untouched, per-parameter step not advanced; the EMA shadow still follows p);
+ * r_mode 2 = the range is updated with its own bias corrections r_bc1, r_bc2 (its step count lags). r_mode 0: ignored. */
 int vd_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n,
                  const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
-                 float bc1, float bc2, float ema_decay, void* stream);
+                 float bc1, float bc2, float ema_decay, int64_t r_lo, int64_t r_hi, int32_t r_mode, float r_bc1, float r_bc2,
+                 void* stream);
 
 #ifdef __cplusplus
 }

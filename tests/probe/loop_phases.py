@@ -3,6 +3,8 @@ in the LDS-read + MFMA section, and waiting (vmcnt + barrier), per workgroup.  p
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "v-diffusion-torch_amd")]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _probe_lib  # noqa: F401,E402  (loads libvdiff_hip_probe.so: the product library has no probe code)
 os.environ["VD_GEMM_PROBE"] = "32"
 import ctypes as C_
 import torch

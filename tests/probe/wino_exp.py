@@ -7,6 +7,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "v-diffusion-torch_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _probe_lib  # noqa: F401,E402  (loads libvdiff_hip_probe.so: the product library has no probe code)
 from v_diffusion import _hip as H
 
 DEV = "cuda"

@@ -12,11 +12,20 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _header_symbols():
+    """(product symbols, probe-only symbols) declared by include/vdiff_hip.h; the latter sit inside #ifdef VD_PROBES"""
+    hdr = open(os.path.join(ROOT, "include", "vdiff_hip.h")).read()
+    probe_txt = "".join(re.findall(r"#ifdef VD_PROBES(.*?)#endif", hdr, re.S))
+    prod_txt = re.sub(r"#ifdef VD_PROBES.*?#endif", "", hdr, flags=re.S)
+    sym = lambda txt: sorted(set(re.findall(r"\b(vd_[a-z0-9_]+)\s*\(", txt)))
+    return sym(prod_txt), sym(probe_txt)
+
+
 def test_c_abi_exports_every_declared_symbol():
     from v_diffusion import _hip
-    hdr = open(os.path.join(ROOT, "include", "vdiff_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(vd_[a-z0-9_]+)\s*\(", hdr)))
+    declared, probe_only = _header_symbols()
     assert declared == sorted(_hip.EXPORTS), "binding table and header disagree"
+    assert probe_only == sorted(_hip.PROBE_EXPORTS)
     if not os.path.exists(_hip.LIB_PATH):
         pytest.fail(f"{_hip.LIB_PATH} missing: run __graft_entry__.build()")
     lib = ctypes.CDLL(_hip.LIB_PATH)
@@ -24,6 +33,35 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} not exported"
     lib.vd_version.restype = ctypes.c_int
     assert lib.vd_version() == 100
+
+
+def test_product_library_has_no_probe_or_experiment_code():
+    """Round-2 review: the shipped .so honoured VD_WINO_EXP (timing variants that compute WRONG results) and exported
+    vd_wino_set_probe.  Those live in libvdiff_hip_probe.so now (-DVD_PROBES, tests/probe/ only): the product library must not
+    export the probe entry point, must not read the probe / experiment knobs, and must not contain a PROBE / EXP instantiation."""
+    from v_diffusion import _hip
+    assert os.path.basename(_hip.LIB_PATH) == "libvdiff_hip.so" or os.environ.get("VDIFF_HIP_LIB")
+    prod_path = os.path.join(ROOT, "v-diffusion-torch_amd", "lib", "libvdiff_hip.so")
+    probe_path = os.path.join(ROOT, "v-diffusion-torch_amd", "lib", "libvdiff_hip_probe.so")
+    prod = ctypes.CDLL(prod_path)
+    _, probe_only = _header_symbols()
+    for name in probe_only:
+        assert not hasattr(prod, name), f"product library exports {name}"
+    blob = open(prod_path, "rb").read()
+    for knob in (b"VD_WINO_EXP", b"VD_GEMM_PROBE", b"VD_WINO_PROBE_LIGHT", b"VD_WGRAD_EXP"):
+        assert knob not in blob, f"product library reads {knob.decode()}"
+    # mangled template arguments <TW, NS, STATS, PROBE, EXP> of wino_conv_kernel: ...Lb<stats>ELb<probe>ELi<exp>E
+    inst = set(re.findall(rb"wino_conv_kernelILi\d+ELi\d+ELb[01]ELb([01])ELi(\d+)E", blob))
+    assert inst == {(b"0", b"0")}, f"probe / experiment instantiations in the product library: {sorted(inst)}"
+    if os.path.exists(probe_path):                        # the probe build keeps them (and nothing in the package loads it)
+        pblob = open(probe_path, "rb").read()
+        assert b"VD_WINO_EXP" in pblob and hasattr(ctypes.CDLL(probe_path), "vd_wino_set_probe")
+    pkg = os.path.join(ROOT, "v-diffusion-torch_amd", "v_diffusion")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            code = [l for l in open(os.path.join(pkg, fn)) if not l.lstrip().startswith("#")]
+            assert not any("libvdiff_hip_probe" in l for l in code), fn       # (comments may name it)
+    assert "libvdiff_hip_probe" not in open(os.path.join(ROOT, "bench.py")).read()
 
 
 def test_gemm_desc_layout_matches_header(tmp_path):
@@ -366,17 +404,9 @@ def test_no_kernel_spills_to_scratch(tmp_path):
     total = 0
     for f, ks in res:
         total += len(ks)
-        # (SGPR spills go to VGPR lanes, not to memory.)  One family is held to a weaker rule: the persistent Winograd convolution
-        # runs three waves per SIMD (168 registers) and parks a handful of per-item constants in scratch OUTSIDE its K loop
-        # (one store per workgroup, one reload per ~90 000-cycle work item); its K loop must stay scratch-free.
-        wino = lambda name: "wino_conv_kernel" in name or "wino_conv_wide_kernel" in name      # (the wide form: 8 waves of 256 registers)
-        bad = [k for k in ks if (k["spill"] or k["scratch"]) and not wino(k["name"])]
+        # (SGPR spills go to VGPR lanes, not to memory.)  No exemptions: round 2 held the persistent Winograd convolution to a
+        # weaker rule (2-5 spilled VGPRs outside its K loop); its per-item lane constants are now re-derived per item and its
+        # epilogue offsets are 32-bit, so it is spill-free like everything else.
+        bad = [k for k in ks if k["spill"] or k["scratch"]]
         assert not bad, f"{f}: kernels with spills / scratch: {bad[:4]}"
-        for k in ks:
-            if wino(k["name"]):
-                assert k["spill"] <= 24, k
-        if f == "wino.hip":
-            inner = scratch_in_inner_loops(open(str(tmp_path / (f + ".s"))).read())
-            hot = {n: c for n, c in inner.items() if wino(n) and c}
-            assert not hot, f"scratch traffic inside the K loop: {hot}"
-    assert total > 100
+    assert total > 90

@@ -754,20 +754,22 @@ def test_kernel_variants_in_subprocess(H, knobs):
 @pytest.mark.parametrize("wide", ["1", "0"])
 def test_wino_forms_in_subprocess(H, wide):
     """The launcher picks between the 64-tile and the 128-tile ("wide") form of the Winograd convolution by how the items fill
-    the residency rounds, so a plain run sends the small parity cases to the 64-tile form and the benchmark shapes to the wide
-    one.  VD_WINO_WIDE forces one form for every geometry it serves: the ragged / multi-image / partial-channel-block cases
-    through the wide kernel (1), the benchmark shapes through the 64-tile kernel (0)."""
+    the residency rounds, so a plain run sends the small parity cases to the 64-tile form and most benchmark shapes to the wide
+    one.  VD_WINO_WIDE forces one form for every geometry it serves; both selected tests call vd_conv3x3_wino and assert the
+    instantiation through vd_wino_last_kernel (tests/test_bench_shapes_gpu.py::_expected_wino mirrors the forced choice):
+      1: the ragged / multi-image / partial-channel-block cases and 576->576 @16x16 at B = 128 through the wide kernel;
+      0: the benchmark launches (B = 128: 32x32x256, 64x64x192, ...) through the 64-tile kernel's multi-round item loop."""
     import os
     import subprocess
     import sys
     env = dict(os.environ, VD_WINO_WIDE=wide)
     here = os.path.dirname(os.path.abspath(__file__))
-    files = [os.path.join(here, "test_kernels_gpu.py")] + ([os.path.join(here, "test_bench_shapes_gpu.py")] if wide == "0" else [])
+    files = [os.path.join(here, "test_kernels_gpu.py"), os.path.join(here, "test_bench_shapes_gpu.py")]
     r = subprocess.run([sys.executable, "-m", "pytest", *files, "-q", "-x", "--no-header", "-p", "no:cacheprovider", "-k",
-                        "conv3x3_wino_forward_stats_dgrad or conv3x3_stats_at_bench_shapes or conv3x3_dgrad_at_bench_shape"],
-                       env=env, capture_output=True, text=True, timeout=900)
+                        "conv3x3_wino_forward_stats_dgrad or wino_conv_at_bench_launches"],
+                       env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    assert " passed" in r.stdout and "19 passed" in r.stdout, r.stdout[-500:]      # 12 geometry cases + 7 bench launches
 
 
 # ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) convolution

@@ -1,6 +1,8 @@
 // api.cpp -- version / error plumbing of the C ABI (include/vdiff_hip.h)
 #include <stdarg.h>
 #include <stdio.h>
+#include <atomic>
+#include <hip/hip_runtime_api.h>
 #include "../../include/vdiff_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -14,3 +16,17 @@ void vd_set_error(const char* fmt, ...) {
 
 extern "C" int vd_version(void) { return VD_VERSION; }
 extern "C" const char* vd_last_error(void) { return g_err; }
+
+// persistent / round-sized launches size themselves by the CU count of the device they run on: cached per device id (a process
+// may drive several devices), lock-free (any thread may launch)
+int vd_cu_count(void) {
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}

@@ -10,7 +10,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// -DVD_PROBES builds libvdiff_hip_probe.so (tests/probe/: in-kernel timestamps, timing-only kernel variants that compute WRONG
+// results).  The product library is built without it: every probe branch below is guarded by this constant and folds away, and
+// no environment variable can reach a wrong-result path.
+#ifdef VD_PROBES
+constexpr bool VD_PROBE_BUILD = true;
+#else
+constexpr bool VD_PROBE_BUILD = false;
+#endif
+
 void vd_set_error(const char* fmt, ...);
+int vd_cu_count(void);                       // compute units of the calling thread's current device (cached per device id)
 extern thread_local int vd_g_last_tile;      // code of the calling thread's last matmul-shaped launch (vd_gemm_last_tile)
 
 #define VD_REQUIRE(cond, ...)                                   \

@@ -34,12 +34,16 @@ struct GemmArgs {
     int kt_total, kt_per_split;
     long long slab_stride;
     float* colsum; int colsum_accumulate;     // COL-kind A only: colsum[m] (+)= sum_k A[k][m]  (bias gradients ride along)
-    int probe;                                // timing experiments only (VD_GEMM_PROBE): bit0/bit1 drop the A/B tile loads, bit2 the
+    int probe;                                // -DVD_PROBES builds only (VD_GEMM_PROBE; always 0 in the product library): bit0/bit1 drop the A/B tile loads, bit2 the
                                               // barrier, bit4 = phase timestamps through `colsum`, bit5 = loop-phase cycles through `stats`
     float* stats; int stats_hw;               // GroupNorm partials of the OUTPUT: [img][chunk][2][N], chunk = BM/2 output rows
     long long sBias;                          // bias offset per batch entry zb
     int lgW, lgHW;                            // log2 of W and H*W when both are powers of two, else -1 (shift/mask instead of divisions)
 };
+
+// timing-probe bits: compiled out of the product library (VD_PROBE_BUILD is a constant: every `PB(p) & bit` branch folds away);
+// -DVD_PROBES builds (libvdiff_hip_probe.so, tests/probe/) read them from VD_GEMM_PROBE
+__device__ __forceinline__ int PB(const GemmArgs& p) { return VD_PROBE_BUILD ? p.probe : 0; }
 
 __device__ __forceinline__ int row_swz(int row, int chunk) { return row * KT + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
@@ -578,8 +582,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
     auto issue_tiles = [&](int buf, const Prep& P) {
         float* as = smem + buf * (BM * KT);
         float* bs = smem + 2 * BM * KT + buf * (BN * KT);
-        const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.pA, p.probe & 1 ? 0 : (int)OOB);   // probe: timing-only build knob
-        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.pB, p.probe & 2 ? 0 : (int)OOB);
+        const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.pA, PB(p) & 1 ? 0 : (int)OOB);   // probe: timing-only build knob
+        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.pB, PB(p) & 2 ? 0 : (int)OOB);
 #pragma unroll
         for (int j = 0; j < AIT; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(as + (j * 4 + wave) * 256), 16, (int)P.vA[j], 0, 0, 0);
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
     const bool do_cs = (AK == VD_COL) && p.colsum != nullptr && tbx == 0 && (wave & 1) == 0;
     // timing probe (VD_GEMM_PROBE bit 4, tests/probe/stamps.py): per-workgroup 100 MHz timestamps {start, main loop done,
     // epilogue issued, stores drained} written through the colsum pointer
-    const bool dbg = (p.probe & 16) != 0;
+    const bool dbg = (PB(p) & 16) != 0;
     unsigned long long ts0 = 0, ts2 = 0;
     if (dbg) ts0 = __builtin_amdgcn_s_memrealtime();
 
@@ -710,13 +714,13 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int buf = 0;
-        if (p.probe & 4) {           // timing probe only (wrong results): no barrier in the main loop
+        if (PB(p) & 4) {           // timing probe only (wrong results): no barrier in the main loop
             for (int kt = kt_begin; kt < kt_end; ++kt) {
                 if (!ISSUE_IN) issue_tiles(buf ^ 1, P);
                 compute(buf, kt + 2, P);
                 buf ^= 1;
             }
-        } else if (p.probe & 32) {      // timing probe: core-clock cycles this wave spends issuing DMA / computing / waiting
+        } else if (PB(p) & 32) {      // timing probe: core-clock cycles this wave spends issuing DMA / computing / waiting
             unsigned long long t_dma = 0, t_cmp = 0, t_wait = 0;
             for (int kt = kt_begin; kt < kt_end; ++kt) {
                 if (!ISSUE_IN) issue_tiles(buf ^ 1, P);
@@ -832,7 +836,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
         return;
     }
     const int row_lane = wm + (A2 ? 8 : 4) * lh;
-    const bool want_stats = !SPLITK && p.stats != nullptr && !(p.probe & 32), edge = rows_valid < BM;       // both uniform
+    const bool want_stats = !SPLITK && p.stats != nullptr && !(PB(p) & 32), edge = rows_valid < BM;       // both uniform
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
         const int ncol = wn + (B2 ? 2 * li + b : 32 * b + li);
@@ -1123,7 +1127,10 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     if ((conv || wgrad) && (d.W & (d.W - 1)) == 0 && ((d.H * d.W) & (d.H * d.W - 1)) == 0) {
         a.lgW = __builtin_ctz((unsigned)d.W); a.lgHW = __builtin_ctz((unsigned)(d.H * d.W));
     }
+    a.probe = 0;
+#ifdef VD_PROBES
     { static const char* e = getenv("VD_GEMM_PROBE"); a.probe = e ? atoi(e) : 0; }
+#endif
     VD_REQUIRE((a.probe & 16) || !(d.colsum && (ak != VD_COL || batch > 1)), "vd_gemm: colsum needs a COL-kind A operand and batch 1");
 
     const int tile = choose_tile(d.M, wgrad ? d.Cin : d.N, wgrad, (long long)batch * splitk, d.tile);

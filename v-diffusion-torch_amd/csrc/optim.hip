@@ -29,22 +29,32 @@ __global__ void sumsq_final_kernel(const float* part, int nb, float* out) {
     if (threadIdx.x == 0) out[0] = (float)sh[0];
 }
 
+// [r_lo, r_hi): an index range with its own treatment this step (the class-embedding tensors, reference unet.py:207-215):
+//   r_mode 1: the range received NO gradient (class-conditional network called with y = None: the reference leaves .grad None
+//             and torch.optim.AdamW skips the parameter -- no moment decay, no weight decay, no update, step not advanced);
+//             p, m, v stay untouched, the EMA shadow still follows p (utils.py:144-149 walks every parameter);
+//   r_mode 2: the range is updated with its own bias corrections r_bc1 / r_bc2 (its per-parameter step count lags the rest).
 __global__ void adamw_ema_kernel(float* p, const float* g, float* m, float* v, float* ema, long long n, const float* gnorm_sq,
                                  float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                 float ema_decay) {
+                                 float ema_decay, long long r_lo, long long r_hi, int r_mode, float r_bc1, float r_bc2) {
     float clip = 1.f;
     if (gnorm_sq && max_norm > 0.f) {
         const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);          // torch clip_grad_norm_
         clip = c < 1.f ? c : 1.f;
     }
     const float step = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+    const float r_step = lr / r_bc1, r_rs2 = 1.f / sqrtf(r_bc2);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * clip;
-        float pi = p[i] * (1.f - lr * wd);
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        pi -= step * mi / (sqrtf(vi) * rs2 + eps);
-        p[i] = pi; m[i] = mi; v[i] = vi;
+        const bool in_r = r_mode != 0 && i >= r_lo && i < r_hi;
+        float pi = p[i];
+        if (!(in_r && r_mode == 1)) {
+            const float gi = g[i] * clip;
+            pi *= 1.f - lr * wd;
+            const float mi = b1 * m[i] + (1.f - b1) * gi;
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            pi -= (in_r ? r_step : step) * mi / (sqrtf(vi) * (in_r ? r_rs2 : rs2) + eps);
+            p[i] = pi; m[i] = mi; v[i] = vi;
+        }
         if (ema) ema[i] += (1.f - ema_decay) * (pi - ema[i]);
     }
 }
@@ -66,11 +76,15 @@ extern "C" int vd_sumsq(const float* g, int64_t n, float* out1, float* ws, size_
 
 extern "C" int vd_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gnorm_sq,
                             float max_norm, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                            float ema_decay, void* stream) {
+                            float ema_decay, int64_t r_lo, int64_t r_hi, int32_t r_mode, float r_bc1, float r_bc2, void* stream) {
+    VD_REQUIRE(r_mode >= 0 && r_mode <= 2, "vd_adamw_ema: r_mode must be 0, 1 or 2");
+    VD_REQUIRE(r_mode == 0 || (0 <= r_lo && r_lo <= r_hi && r_hi <= n), "vd_adamw_ema: bad range [%lld, %lld)", (long long)r_lo, (long long)r_hi);
+    VD_REQUIRE(r_mode != 2 || (r_bc1 > 0.f && r_bc2 > 0.f), "vd_adamw_ema: r_mode 2 needs positive bias corrections");
     long long grid = (n + 255) / 256;
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (long long)n,
-                       gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay);
+                       gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay, (long long)r_lo, (long long)r_hi, (int)r_mode,
+                       r_mode == 2 ? r_bc1 : 1.f, r_mode == 2 ? r_bc2 : 1.f);
     VD_LAUNCH_CHECK("adamw_ema_kernel");
     return 0;
 }

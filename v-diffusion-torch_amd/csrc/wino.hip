@@ -53,8 +53,8 @@ struct WinoArgs {
     float invP2, invRIN;                       // 1 / (2 P), 1 / RIN (prologue index arithmetic without integer division)
     int ntiles;                                // nimg * TPI
     int ncb, ntg;                              // work items: channel blocks x tile groups
-    unsigned long long* probe;                 // timing probe build only (vd_wino_set_probe): 8 x u64 per workgroup
-    int probe_light;                           // probe build: stamps at kernel start / end only (VD_WINO_PROBE_LIGHT: no per-barrier s_memtime)
+    unsigned long long* probe;                 // -DVD_PROBES builds only (libvdiff_hip_probe.so, vd_wino_set_probe): 8 x u64 per workgroup
+    int probe_light;                           // -DVD_PROBES builds: stamps at kernel start / end only (VD_WINO_PROBE_LIGHT: no per-barrier s_memtime)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
@@ -83,6 +83,7 @@ __device__ __forceinline__ int b_swz(int row) { return (row >> 2) & 2; }
 // prefetch of the first U fragments of t+1, step 7.  One more barrier per item separates the epilogue's LDS exchange (in the
 // dead U stage) and the read of patch'(0) from the loader's next overwrite.
 constexpr int WINO_THREADS = 768;
+// PROBE / EXP are instantiated by -DVD_PROBES builds only (libvdiff_hip_probe.so, tests/probe/): the product library has neither.
 // EXP != 0: timing experiments only (WRONG results; VD_WINO_EXP, tests/probe/wino_exp.py): 1 = no input-transform arithmetic,
 // 2 = also no patch reads, 3 = also no U-fragment reads, 4 = everything but no tile barrier in the compute waves' K loop,
 // 5 = like 3 and the loaders issue no DMA (the MFMA + epilogue skeleton alone), 6 = full arithmetic but only half of the U DMA pieces
@@ -250,14 +251,22 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
     for (int n = 0; have; ++n) {
         const int co0 = tbx * TN;
         const int tile0 = tby * TILES_WG;                           // first tile of the item
-        const int trow0 = (tile0 & (p.TPI - 1)) >> LGTW;            // first tile row inside its image (0 when an item spans images)
-        const int tl = 16 * tg + li;                                // this lane's tile inside the item
+        // Per-item lane constants are RE-DERIVED here from the lane id (a volatile v_mbcnt pair) and from scalars passed through
+        // optimisation barriers instead of being kept live across the K loop: the loop runs at the 168-register cap of three
+        // waves per SIMD, and everything loop-invariant the compiler hoists out of the item loop ends up parked in scratch.
+        int lane_i;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_i));
+        const int li_i = lane_i & 15, lq_i = lane_i >> 4;
+        int tpim = p.TPI - 1, lgtpi = p.lgTPI, rin = p.RIN;
+        asm volatile("" : "+s"(tpim), "+s"(lgtpi), "+s"(rin));
+        const int trow0 = (tile0 & tpim) >> LGTW;                   // first tile row inside its image (0 when an item spans images)
+        const int tl = 16 * tg + li_i;                              // this lane's tile inside the item
         const int tile = tile0 + tl;
-        const int il = tl >> p.lgTPI;                               // local image (0 unless the item spans images)
-        const int tin = (tile & (p.TPI - 1));                       // tile inside its image
+        const int il = tl >> lgtpi;                                 // local image (0 unless the item spans images)
+        const int tin = (tile & tpim);                              // tile inside its image
         const int ty = tin >> LGTW, tx = tin & (TW - 1);
-        const int slot0 = ((il * p.RIN + 2 * (ty - trow0)) * 2) * P + tx;    // slot of patch position (p=0, q=0), chunk 0
-        const float* pbase = sA + (lq * NS + slot0) * 4;            // + chunk lq
+        const int slot0 = ((il * rin + 2 * (ty - trow0)) * 2) * P + tx;      // slot of patch position (p=0, q=0), chunk 0
+        const float* pbase = sA + (lq_i * NS + slot0) * 4;          // + chunk lq
         const float* pr0 = pbase + rrow0 * P2 * 4;
         const float* pr1 = pbase + rrow1 * P2 * 4;
         const float* pr2 = pbase + rrow2 * P2 * 4;
@@ -373,7 +382,9 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
         const int ty_e = tin_e >> LGTW, tx_e = tin_e & (TW - 1);
         const bool tile_ok = tile_e < p.ntiles;
         const int img = tile_e >> p.lgTPI;
-        const long long pix00 = ((long long)img * p.H + 2 * ty_e) * p.W + 2 * tx_e;
+        // (32-bit offsets: vd_conv3x3_wino_supported bounds pixels * ld * 4 below 2^31 for x, y and the residual)
+        const unsigned pix00 = (unsigned)((img * p.H + 2 * ty_e) * p.W + 2 * tx_e);
+        const unsigned ldr_u = (unsigned)p.ldr, ldy_u = (unsigned)p.ldy;
         const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
         const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
         const int co = co0 + 16 * ah + 4 * lq_e;
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
-                const unsigned vor = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldr + co) * 4) : OOB;
+                const unsigned vor = ok ? ((pix00 + (unsigned)(u * p.W + v)) * ldr_u + (unsigned)co) * 4u : OOB;
                 r4[u][v] = p.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         f32x4 PT[2][2][2];                   // [cb][u][v]
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_conv_kernel(const WinoArgs 
             for (int v = 0; v < 2; ++v) {
                 const f32x4 val = (PT[ah][u][v] + b4) + r4[u][v];
                 if (STATS) { a1 += val; a2 += val * val; }
-                const unsigned voc = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldy + co) * 4) : OOB;
+                const unsigned voc = ok ? ((pix00 + (unsigned)(u * p.W + v)) * ldy_u + (unsigned)co) * 4u : OOB;
                 const u32x4 wv = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
                 __builtin_amdgcn_raw_buffer_store_b128(wv, yrs, (int)voc, 0, 0);
             }
@@ -484,7 +495,8 @@ __device__ __forceinline__ void wino_store_outputs(const WinoArgs& p, const f32x
     const int tin = tile & (p.TPI - 1);
     const int ty = tin >> LGTW, tx = tin & (TW - 1);
     const int img = tile >> p.lgTPI;
-    const long long pix00 = ((long long)img * p.H + 2 * ty) * p.W + 2 * tx;
+    const unsigned pix00 = (unsigned)((img * p.H + 2 * ty) * p.W + 2 * tx);      // (32-bit: see vd_conv3x3_wino_supported)
+    const unsigned ldr_u = (unsigned)p.ldr, ldy_u = (unsigned)p.ldy;
     const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
     const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
     const bool ok = tile < p.ntiles && co < p.Cout;                 // (Cout is a multiple of 4)
@@ -495,7 +507,7 @@ __device__ __forceinline__ void wino_store_outputs(const WinoArgs& p, const f32x
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-            const unsigned vor = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldr + co) * 4) : OOB;
+            const unsigned vor = ok ? ((pix00 + (unsigned)(u * p.W + v)) * ldr_u + (unsigned)co) * 4u : OOB;
             r4[u][v] = p.res ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)vor, 0, 0)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
@@ -505,7 +517,7 @@ __device__ __forceinline__ void wino_store_outputs(const WinoArgs& p, const f32x
         for (int v = 0; v < 2; ++v) {
             const f32x4 val = (F[u][v] + b4) + r4[u][v];
             if (STATS) { a1 += val; a2 += val * val; }
-            const unsigned voc = ok ? (unsigned)(((pix00 + u * p.W + v) * p.ldy + co) * 4) : OOB;
+            const unsigned voc = ok ? ((pix00 + (unsigned)(u * p.W + v)) * ldy_u + (unsigned)co) * 4u : OOB;
             const u32x4 wv = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
             __builtin_amdgcn_raw_buffer_store_b128(wv, yrs, (int)voc, 0, 0);
         }
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void wino_conv_wide_kernel(const Wino
     const int G = gridDim.x, w = blockIdx.x;
     const int nitems = p.ncb * p.ntg;
     unsigned long long pt0 = 0, pr0 = 0;                            // vd_wino_set_probe: clock stamps at kernel start / end
-    if (p.probe) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
+    if (VD_PROBE_BUILD && p.probe) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     auto item_of = [&](int n, int& tbx, int& tby) -> bool {
         int t = n * G + w;
         if ((G & 7) == 0 && (n + 1) * G <= nitems) t = n * G + (w & 7) * (G >> 3) + (w >> 3);
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void wino_conv_wide_kernel(const Wino
         }
         have = next; tbx = nbx; tby = nby;
     }
-    if (p.probe && lane == 0) {
+    if (VD_PROBE_BUILD && p.probe && lane == 0) {
         // same record as the narrow kernel's probe (8 x u64 per wave): start, -, -, end, -, realtime at start, K tiles, realtime at end
         unsigned long long* o = p.probe + ((unsigned long long)blockIdx.x * 8 + wave) * 8;
         o[0] = pt0; o[1] = pt0; o[2] = pt0; o[3] = __builtin_amdgcn_s_memtime(); o[4] = 0; o[5] = pr0; o[6] = (unsigned long long)nkt;
@@ -842,8 +854,13 @@ __global__ __launch_bounds__(256) void wino_pack_batched_kernel(const long long*
     else wino_pack_one(w, uf, ud, (int)it[3], (int)it[4], (long long)local * blockDim.x + threadIdx.x);
 }
 
-unsigned long long* g_probe = nullptr;
-thread_local int g_last_wino = 0;       // (TW * 1000 + NS) * 2 + stats of the calling thread's last vd_conv3x3_wino launch
+#ifdef VD_PROBES
+unsigned long long* g_probe = nullptr;  // probe library only (vd_wino_set_probe)
+#else
+constexpr unsigned long long* g_probe = nullptr;
+#endif
+thread_local int g_last_wino = 0;       // (TW * 1000 + NS) * 2 + stats of the calling thread's last vd_conv3x3_wino launch (negative: wide form)
+thread_local int g_last_wgrad = 0;      // (TWS * 1000 + slabs) * 2 + dbias of the calling thread's last vd_conv3x3_wgrad_wino launch
 
 inline int ilog2(int v) { return 31 - __builtin_clz((unsigned)v); }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -902,14 +919,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
                "vd_conv3x3_wino: unsupported geometry nimg=%d H=%d W=%d Cin=%d Cout=%d (use vd_conv3x3)", nimg, H, W, Cin, Cout);
     VD_REQUIRE(vd_aligned16(xin) && vd_aligned16(U) && vd_aligned16(y) && (!res || vd_aligned16(res)) && (!bias || vd_aligned16(bias)),
                "vd_conv3x3_wino: operands must be 16-byte aligned");
-    static int ncu = 0;                       // persistent workgroups: one per CU (the LDS footprint admits no second one)
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
-        else ncu = 256;
-    }
+    const int ncu = vd_cu_count();            // persistent workgroups: one per CU (the LDS footprint admits no second one)
     {
         // wide form (128-tile items, ~5 % faster per unit of work: same-box A/B in tests/perf_wino.py) wherever its items fill the
         // residency rounds at least as well as the 64-tile items do: rounds x 2 x 0.95 against the narrow form's rounds
@@ -961,9 +971,10 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
     VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_wino: too many work items");
     const dim3 grid((unsigned)(items < ncu ? items : ncu));
     hipStream_t st = (hipStream_t)stream;
+    const dim3 blk(WINO_THREADS);
+#ifdef VD_PROBES
     a.probe = g_probe;
     { static const bool light = getenv("VD_WINO_PROBE_LIGHT") != nullptr; a.probe_light = light ? 1 : 0; }
-    const dim3 blk(WINO_THREADS);
 #define VD_WINO_LAUNCH(TWV, NSV)                                                                                                   \
     do {                                                                                                                            \
         g_last_wino = ((TWV) * 1000 + (NSV)) * 2 + (stats_part ? 1 : 0);                                                            \
@@ -973,7 +984,8 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
         } else if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, true>), grid, blk, 0, st, a);                          \
         else hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, false>), grid, blk, 0, st, a);                                           \
     } while (0)
-    static const int exp_mode = getenv("VD_WINO_EXP") ? atoi(getenv("VD_WINO_EXP")) : 0;       // timing experiments (wrong results)
+    // timing experiments (WRONG results): probe library only -- the product library has no such instantiation and reads no such knob
+    static const int exp_mode = getenv("VD_WINO_EXP") ? atoi(getenv("VD_WINO_EXP")) : 0;
     if (exp_mode && g.TW == 16 && g.NS <= 384 && !stats_part) {
 #define VD_WINO_EXP_LAUNCH(E)                                                                                                      \
         do {                                                                                                                        \
@@ -988,8 +1000,17 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
         else VD_WINO_EXP_LAUNCH(4);
 #undef VD_WINO_EXP_LAUNCH
         VD_LAUNCH_CHECK("wino_conv_kernel(exp)");
+        g_last_wino = 0;
         return 0;
     }
+#else
+#define VD_WINO_LAUNCH(TWV, NSV)                                                                                                   \
+    do {                                                                                                                            \
+        g_last_wino = ((TWV) * 1000 + (NSV)) * 2 + (stats_part ? 1 : 0);                                                            \
+        if (stats_part) hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, true>), grid, blk, 0, st, a);                                 \
+        else hipLaunchKernelGGL((wino_conv_kernel<TWV, NSV, false>), grid, blk, 0, st, a);                                           \
+    } while (0)
+#endif
     // (tiles per row, patch slots): the square images of the shipped configs take the first form of each row
     if (g.TW == 16 && g.NS <= 384) VD_WINO_LAUNCH(16, 384);
     else if (g.TW == 8 && g.NS <= 384) VD_WINO_LAUNCH(8, 384);
@@ -1008,8 +1029,11 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
 
 /* timing probe only: device buffer of 64 u64 per workgroup (8 per wave: start, loop start, loop end, end, cycles at the tile
  * barrier, 100 MHz realtime at start, K tiles, realtime at end), or NULL to switch the probe off */
+#ifdef VD_PROBES
 extern "C" int vd_wino_set_probe(unsigned long long* buf) { g_probe = buf; return 0; }
+#endif
 extern "C" int vd_wino_last_kernel(void) { return g_last_wino; }
+extern "C" int vd_wino_wgrad_last_kernel(void) { return g_last_wgrad; }
 
 extern "C" int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf, float* ud, void* stream) {
     VD_REQUIRE(w_oihw && (uf || ud), "vd_wino_pack: null pointer");
@@ -1063,7 +1087,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
     constexpr int NR = WG_T / TWS, P = TWS + 1, P2 = 2 * P, LG = TWS == 16 ? 4 : (TWS == 8 ? 3 : 2);
     static_assert((2 * NR + 2) * P2 <= WG_NSX, "patch image too large");
     unsigned long long pt0 = 0, pr0 = 0;
-    if (p.probe) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
+    if (VD_PROBE_BUILD && p.probe) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WG_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1304,7 +1328,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
         const int co = co0 + 32 * mh + 2 * lm;
         if (kq == 0 && co < p.Cout) *reinterpret_cast<f32x2*>(p.cpart + (long long)z * p.Cout + co) = bsum;
     }
-    if (p.probe && threadIdx.x == 0) {
+    if (VD_PROBE_BUILD && p.probe && threadIdx.x == 0) {
         unsigned long long* o = p.probe + 4ull * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         o[0] = pt0; o[1] = pr0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
     }
@@ -1340,6 +1364,7 @@ struct WgPlan { bool ok; int TW, TH, TPI, TWs, NR, nstages, S, per; };
 
 static WgPlan wgrad_plan_wino(int nimg, int H, int W, int Cin, int Cout) {
     WgPlan g = {};
+    const int ncu = vd_cu_count();
     if (H % 2 || W % 2 || Cin % 4 || Cout % 4 || nimg <= 0) return g;
     g.TW = W / 2; g.TH = H / 2;
     g.TPI = g.TW * g.TH;
@@ -1348,14 +1373,14 @@ static WgPlan wgrad_plan_wino(int nimg, int H, int W, int Cin, int Cout) {
     g.NR = WG_T / g.TWs;
     if (g.NR > g.TH) return g;
     g.nstages = nimg * g.TPI / WG_T;
-    // slabs: one workgroup per CU and round (100 KB of LDS each); pick the count that fills whole rounds of 256 best, >= 4 stages each
+    // slabs: one workgroup per CU and round (100 KB of LDS each); pick the count that fills whole rounds of the device's CUs best, >= 4 stages each
     const long long blocks = ((Cout + 63) / 64) * (long long)((Cin + 63) / 64);
     int best = 1;
     double best_eff = 0.0;
     for (int S = 1; S <= 64 && S <= g.nstages; ++S) {
         if (S > 1 && g.nstages / S < 4) break;
-        const long long wgs = blocks * S, rounds = (wgs + 255) / 256;
-        double eff = (double)wgs / (double)(rounds * 256);
+        const long long wgs = blocks * S, rounds = (wgs + ncu - 1) / ncu;
+        double eff = (double)wgs / (double)(rounds * ncu);
         eff *= 1.0 - 0.002 * S;                        // mild preference for fewer slabs (less reduce traffic)
         if (eff > best_eff) { best_eff = eff; best = S; }
     }
@@ -1404,6 +1429,7 @@ static int wgrad_wino_impl(const float* xin, int64_t ldx, const float* dy, int64
         else hipLaunchKernelGGL((wino_wgrad_kernel<T, false>), grid, dim3(512), 0, st, a);       \
     } while (0)
     if (phases & 1) {
+        g_last_wgrad = (g.TWs * 1000 + g.S) * 2 + (dbias ? 1 : 0);
         if (g.TWs == 16) VD_WG_LAUNCH(16);
         else if (g.TWs == 8) VD_WG_LAUNCH(8);
         else VD_WG_LAUNCH(4);

@@ -41,12 +41,12 @@ _SIGNATURES = {
     "vd_conv3x3_wino_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64]),
     "vd_conv3x3_wino": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vd_wino_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
-    "vd_wino_set_probe": (C.c_int, [_vp]),
     "vd_conv3x3_wgrad_wino_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64]),
     "vd_conv3x3_wgrad_wino_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "vd_conv3x3_wgrad_wino": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_conv3x3_wgrad_wino_phase": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _i32, _vp]),
     "vd_wino_last_kernel": (C.c_int, []),
+    "vd_wino_wgrad_last_kernel": (C.c_int, []),
     "vd_wino_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
@@ -92,9 +92,13 @@ _SIGNATURES = {
     "vd_sample_step": (C.c_int, [_vp, _vp, _vp, C.POINTER(_f32), _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vd_sumsq_ws_bytes": (_sz, [_i64]),
     "vd_sumsq": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
-    "vd_adamw_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "vd_adamw_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _i64, _i32,
+                               _f32, _f32, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
+# extra entry points of libvdiff_hip_probe.so (built with -DVD_PROBES; tests/probe/*.py load it through VDIFF_HIP_LIB): bound when
+# the loaded library has them, absent from the product library
+PROBE_EXPORTS = {"vd_wino_set_probe": (C.c_int, [_vp])}
 
 _lib = None
 
@@ -111,6 +115,10 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)           # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in PROBE_EXPORTS.items():
+            if hasattr(l, name):
+                fn = getattr(l, name)
+                fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
 
@@ -516,6 +524,8 @@ def sumsq(g, out1):
     _check(lib().vd_sumsq(ptr(g), g.numel(), ptr(out1), ws.data_ptr(), ws.numel() * 4, stream()), "vd_sumsq")
 
 
-def adamw_ema(p, g, m, v, ema, gnorm_sq, max_norm, lr, b1, b2, eps, wd, bc1, bc2, ema_decay):
+def adamw_ema(p, g, m, v, ema, gnorm_sq, max_norm, lr, b1, b2, eps, wd, bc1, bc2, ema_decay, r_lo=0, r_hi=0, r_mode=0, r_bc1=1.0,
+              r_bc2=1.0):
+    """r_*: an index range treated apart this step, see vd_adamw_ema (1 = no gradient this step, 2 = own bias corrections)"""
     _check(lib().vd_adamw_ema(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), ptr(gnorm_sq), max_norm, lr, b1, b2, eps,
-                              wd, bc1, bc2, ema_decay, stream()), "vd_adamw_ema")
+                              wd, bc1, bc2, ema_decay, int(r_lo), int(r_hi), int(r_mode), r_bc1, r_bc2, stream()), "vd_adamw_ema")

@@ -44,21 +44,25 @@ def slice_along_batch(x: torch.Tensor, span: int):
 
 
 def _per_sample(logsnr, x):
-    """(B,) float32 log-SNR vector of a per-sample (B,1,1,1)-shaped argument, or None when it is not one value per sample"""
+    """(B,) float32 log-SNR vector of a per-sample argument -- shape (B,) or (B,1,1,1), nothing else: a (1,C,1,1) per-channel
+    tensor with C == B has B elements too, and is NOT one value per sample -- or None"""
     if not torch.is_tensor(logsnr) or not x.is_cuda or x.dtype != torch.float32 or x.ndim != 4:
         return None
-    if logsnr.numel() != x.shape[0] or logsnr.device != x.device:
+    B = x.shape[0]
+    if logsnr.device != x.device or tuple(logsnr.shape) not in ((B,), (B, 1, 1, 1)):
         return None
     return logsnr.reshape(-1).to(torch.float32).contiguous()
 
 
 def q_sample(x_0, logsnr_t, eps=None):
     """x_t = alpha * x_0 + sigma * eps with alpha^2 = sigmoid(logsnr), sigma^2 = sigmoid(-logsnr) (reference :242-245).
-    One per-sample log-SNR per image on the device = the fused ``vd_q_sample`` kernel; other broadcast shapes = the
-    same expression in tensor ops."""
+    One per-sample log-SNR per image on the device, nothing asking for a gradient = the fused ``vd_q_sample`` kernel (it has no
+    autograd node: the reference's q_sample is differentiable in x_0, eps and logsnr, so any input that requires grad under
+    grad mode takes the tensor expression, as do all other broadcast shapes)."""
     if eps is None:
         eps = torch.randn_like(x_0)
-    l = _per_sample(logsnr_t, x_0)
+    wants_grad = torch.is_grad_enabled() and any(torch.is_tensor(a) and a.requires_grad for a in (x_0, logsnr_t, eps))
+    l = None if wants_grad else _per_sample(logsnr_t, x_0)
     if l is not None and eps.shape == x_0.shape and eps.dtype == torch.float32:
         x_0, eps = x_0.contiguous(), eps.contiguous()
         out = torch.empty_like(x_0)
@@ -630,6 +634,7 @@ class GaussianDiffusion:
     # batch-1 step is bound by the per-kernel critical path on the GPU (one 3x3 conv = 72 dependent K tiles), not by the
     # ~250 host launches -- so the graph is opt-in (``use_graph=True``) until small-batch kernels get split-K.
     GRAPH_MAX_ROWS = 0
+    GRAPH_CACHE_MAX = 8
 
     def _graph_eligible(self, denoise_fn, rows, pred_freq):
         net = getattr(denoise_fn, "module", denoise_fn)
@@ -666,8 +671,16 @@ class GaussianDiffusion:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 body()
-            entry = cache[key] = (graph, st)
-        graph, st = entry
+            # the graph's pack / convolution nodes hold raw pointers into the engine's pack state (device table, U images):
+            # keep that state referenced by the cache entry, so an engine-side eviction can never free memory a cached graph
+            # replays through; the graph cache itself is a small LRU (a graph pins its activations)
+            eng = net.engine() if hasattr(net, "engine") else None
+            while len(cache) >= self.GRAPH_CACHE_MAX:
+                cache.pop(next(iter(cache)))
+            entry = cache[key] = (graph, st, None if eng is None else eng._last_pack_state)
+        else:
+            cache[key] = cache.pop(key)                # most recently used last
+        graph, st = entry[0], entry[1]
         st["x"].copy_(x_t)
         if cfg:
             st["xin"].copy_(x_t.repeat_interleave(2, dim=0))

@@ -131,7 +131,8 @@ class UNetEngine:
         # forward weight packs kept across calls while a sampler holds the weights fixed (set to {} by the sampling loop,
         # None otherwise: training repacks every step because the optimizer rewrites the weights)
         self.pack_cache = None
-        self._pack_state = None           # persistent buffers + device table of the batched weight pack
+        self._pack_state = None           # {weight-set key: persistent buffers + device table of the batched weight pack}
+        self._last_pack_state = None
         self._packed = None               # {id(weight): (wf, wd)} valid for the weights as of the last forward
 
     # ------------------------------------------------------------------------------------------ small helpers
@@ -166,40 +167,28 @@ class UNetEngine:
         H.gn_apply(x, _ld(x), stats, gn.weight, gn.bias, film, act, p_drop, seed, rs, y, _ld(y), B, Hh, Ww, C, coef, GROUPS)
         return coef
 
+    PACK_STATES_MAX = 4       # weight sets (raw / EMA) x (training / inference) whose packed images are kept at a time
+
     def _pack_all(self, need_d):
-        """Re-pack the 3x3 kernels of every residual block in ONE launch (vd_pack_conv3x3_batched) into persistent
-        buffers; returns {id(weight): (forward pack, dgrad pack or None)}.  The device table is rebuilt only when a
-        parameter's storage moved (load_state_dict keeps it, an EMA view swap does not)."""
+        """Re-pack the 3x3 kernels of every residual block in ONE launch (vd_wino_pack_batched / vd_pack_conv3x3_batched) into
+        persistent buffers; returns {id(weight): (forward pack, dgrad pack or None)}.
+        Pack state (buffers + device table) is kept PER WEIGHT SET -- the key is the parameters' storage pointers, so raw
+        weights and an EMA view swap (trainer.ema_weights) each keep their own stable buffers and table instead of freeing and
+        re-allocating them on every alternation -- in a small LRU.  ``self._last_pack_state`` is the state the last forward
+        used: a captured HIP graph keeps a reference to it, so the table / U images its pack and convolution nodes point to
+        stay allocated for as long as the graph is cached (diffusion._sample_loop_graph)."""
         ws = [c.weight for b in self.plan if b.res is not None for c in (b.res.conv1, b.res.conv2)]
-        key = tuple(w.data_ptr() for w in ws)
+        key = (bool(need_d), H.WINO) + tuple(w.data_ptr() for w in ws)
         if self._pack_state is None:
             self._pack_state = {}
-        st = self._pack_state.get(bool(need_d))          # training and inference keep separate tables / buffers
-        if st is None or st["key"] != key:
+        st = self._pack_state.pop(key, None)             # (re-inserted below as the most recent entry)
+        if st is None:
             dev = ws[0].device
             sizes = [w.numel() for w in ws]
-            if st is None or st["wf"].numel() != sum(sizes) or st["wf"].device != dev:
-                wf_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-                wd_all = None
-            else:
-                wf_all, wd_all = st["wf"], st["wd"]
-            if need_d and wd_all is None:
-                wd_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-            rows, views, off, blk = [], {}, 0, 0
-            for w, n in zip(ws, sizes):
-                co, ci = w.shape[0], w.shape[1]
-                wf = wf_all[off: off + n].view(co, 9, ci)
-                wd = wd_all[off: off + n].view(ci, 9, co) if need_d else None
-                rows.append([w.data_ptr(), wf.data_ptr(), wd.data_ptr() if need_d else 0, co, ci, ci, co, blk])
-                views[id(w)] = (wf, wd)
-                off += n
-                blk += (n + 255) // 256
-            table = torch.tensor(rows, dtype=torch.int64).to(dev)
-            st = self._pack_state[bool(need_d)] = dict(key=key, wf=wf_all, wd=wd_all, table=table, n=len(ws), blocks=blk, views=views)
+            st = dict(n=len(ws))
             if H.WINO:
                 # Winograd-domain kernels U = G w G^T (csrc/wino.hip): [16][Cout][Cin] forward, [16][Cin][Cout] input gradient
-                old = st.get("uf")
-                uf_all = old if (old is not None and old.numel() == 16 * sum(sizes) // 9) else torch.empty(16 * sum(sizes) // 9, dtype=torch.float32, device=dev)
+                uf_all = torch.empty(16 * sum(sizes) // 9, dtype=torch.float32, device=dev)
                 ud_all = torch.empty_like(uf_all) if need_d else None
                 wrows, wviews, woff, wblk = [], {}, 0, 0
                 for w, n in zip(ws, sizes):
@@ -213,6 +202,23 @@ class UNetEngine:
                     woff += m
                     wblk += (co // 16) * (ci // 16) if tiled else (co * ci + 255) // 256
                 st.update(uf=uf_all, ud=ud_all, wtable=torch.tensor(wrows, dtype=torch.int64).to(dev), wblocks=wblk, wviews=wviews)
+            else:
+                wf_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+                wd_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev) if need_d else None
+                rows, views, off, blk = [], {}, 0, 0
+                for w, n in zip(ws, sizes):
+                    co, ci = w.shape[0], w.shape[1]
+                    wf = wf_all[off: off + n].view(co, 9, ci)
+                    wd = wd_all[off: off + n].view(ci, 9, co) if need_d else None
+                    rows.append([w.data_ptr(), wf.data_ptr(), wd.data_ptr() if need_d else 0, co, ci, ci, co, blk])
+                    views[id(w)] = (wf, wd)
+                    off += n
+                    blk += (n + 255) // 256
+                st.update(wf=wf_all, wd=wd_all, table=torch.tensor(rows, dtype=torch.int64).to(dev), blocks=blk, views=views)
+            while len(self._pack_state) >= self.PACK_STATES_MAX:
+                self._pack_state.pop(next(iter(self._pack_state)))       # least recently used
+        self._pack_state[key] = st
+        self._last_pack_state = st
         if H.WINO:
             # every convolution the Winograd kernels serve needs only U; the direct packs are made per tensor, on demand, by
             # _pack_f / _pack_d for the geometries that fall back (none in the shipped configs)
@@ -338,6 +344,8 @@ class UNetEngine:
         elif m.num_classes:
             # class-conditional network called without labels: the reference leaves these gradients None and its optimizer
             # skips them; every entry of G must be written (flat buffers are reused across steps), so they are exact zeros
+            # here and HotPathTrainer.step tells the fused optimizer kernel to leave that range alone (vd_adamw_ema r_mode 1:
+            # no moment decay, no weight decay, no update, step not advanced -- what torch.optim.AdamW does for grad None)
             for k in G:
                 if k.startswith("class_embed."):
                     G[k].zero_()

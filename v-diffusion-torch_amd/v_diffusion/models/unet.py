@@ -77,7 +77,11 @@ class _UNetFn(torch.autograd.Function):
             # the kernels already wrote into the caller's flat gradient buffer (trainer.FlatState): autograd gets nothing
             # to accumulate, which avoids a 243 MB clone per step
             return (None, dx, None, None) + (None,) * len(G)
-        return (None, dx, None, None) + tuple(G[k] for k, _ in model.named_parameters())
+        # class-conditional network called without labels: the class embedding took no part in the forward, so -- as in the
+        # reference, where autograd never reaches those parameters -- their gradient is None (torch optimizers then skip them)
+        no_labels = bool(model.num_classes) and tape["embed"]["yn"] is None
+        return (None, dx, None, None) + tuple(None if (no_labels and k.startswith("class_embed.")) else G[k]
+                                              for k, _ in model.named_parameters())
 
 
 class UNet(nn.Module):

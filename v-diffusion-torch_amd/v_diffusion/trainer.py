@@ -88,6 +88,19 @@ class FlatState:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.ema_updates = 0
+        # the class-embedding tensors (unet.py:207-215) are the one parameter group that may see no gradient in a step (a class-
+        # conditional network called with y = None: the reference leaves .grad None and torch.optim.AdamW skips those parameters,
+        # so their per-parameter step count lags): a contiguous range at the end of the flat buffers with its own step count
+        cls = [k for k in order if k.startswith("class_embed.")]
+        self.cls_names = set(cls)
+        self.cls_range = None
+        if cls:
+            lo = min(offs[k] for k in cls)
+            hi = max(offs[k] + (params[k].numel() + 3) // 4 * 4 for k in cls)
+            assert all(lo <= offs[k] < hi for k in cls) and not any(lo <= offs[k] < hi for k in order if k not in self.cls_names), \
+                "class-embedding tensors are not contiguous in the flat buffer"
+            self.cls_range = (lo, min(hi, n))
+        self.cls_steps = 0
 
     def ema_state_dict(self):
         """EMA shadow as a reference-format state_dict (utils.py:168-175 keeps ``shadow`` per parameter name)."""
@@ -149,8 +162,11 @@ class HotPathTrainer:
         self.reducer = GradReducer(self.flat, world_size, group=group)
         model._grads_ready_hook = None
         self.generator = torch.Generator(self.device).manual_seed(8191 + rank)       # train_utils.py:124
+        # the leader = first member of the process group (global rank 0 need not belong to a sub-group)
+        self.leader = dist.get_global_rank(group, 0) if (world_size > 1 and group is not None) else 0
+        self.is_leader = world_size == 1 or (dist.get_rank() == self.leader if dist.is_initialized() else rank == 0)
         if world_size > 1:                                                            # DDP ctor broadcast (train.py:148)
-            dist.broadcast(self.flat.p, src=0, group=group)
+            dist.broadcast(self.flat.p, src=self.leader, group=group)
             if self.flat.ema is not None:
                 self.flat.ema.copy_(self.flat.p)
 
@@ -168,6 +184,8 @@ class HotPathTrainer:
         """One micro-batch: returns the detached mean loss (device tensor; no host sync here)."""
         flat = self.flat
         t, noise = self.draw(x)
+        if y is not None:
+            self._cls_grad = True                                  # some micro-batch of this update reached the class embedding
         loss = self.diffusion.train_loss(self.model, x_0=x, t=t, y=y, noise=noise).mean()
         self.reducer.start()
         self.model._grads_ready_hook = self.reducer.ready
@@ -190,11 +208,24 @@ class HotPathTrainer:
             if flat.ema is not None:
                 flat.ema_updates += 1
                 decay = min(self.ema_decay, (1 + flat.ema_updates) / (10 + flat.ema_updates))   # utils.py:145-146
+            rng = {}
+            if flat.cls_range is not None:
+                # reference semantics of parameters without a gradient (torch.optim.AdamW skips them: no moment decay, no weight
+                # decay, no update, their own step counter): see vd_adamw_ema
+                if not getattr(self, "_cls_grad", False):
+                    rng = dict(r_lo=flat.cls_range[0], r_hi=flat.cls_range[1], r_mode=1)
+                else:
+                    flat.cls_steps += 1
+                    if flat.cls_steps != k:
+                        kc = flat.cls_steps
+                        rng = dict(r_lo=flat.cls_range[0], r_hi=flat.cls_range[1], r_mode=2, r_bc1=1 - self.betas[0] ** kc,
+                                   r_bc2=1 - self.betas[1] ** kc)
+            self._cls_grad = False
             _hip.adamw_ema(flat.p, flat.g, flat.m, flat.v, flat.ema, flat.gnorm_sq, float(self.grad_norm), lr, self.betas[0],
-                           self.betas[1], self.eps, self.wd, 1 - self.betas[0] ** k, 1 - self.betas[1] ** k, decay)
+                           self.betas[1], self.eps, self.wd, 1 - self.betas[0] ** k, 1 - self.betas[1] ** k, decay, **rng)
         loss = loss.detach()
         if self.world > 1:                                         # train_utils.py:156-158: the leader reports the rank mean
-            dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM, group=self.reducer.group)
+            dist.reduce(loss, dst=self.leader, op=dist.ReduceOp.SUM, group=self.reducer.group)
             loss.div_(self.world)
         return loss
 
@@ -224,8 +255,10 @@ class HotPathTrainer:
         state = {}
         if flat.step_count > 0:
             for i, k in enumerate(names):
-                state[i] = {"step": torch.tensor(float(flat.step_count)), "exp_avg": view(flat.m, k).clone(),
-                            "exp_avg_sq": view(flat.v, k).clone()}
+                steps = flat.cls_steps if k in flat.cls_names else flat.step_count
+                if steps == 0:
+                    continue                 # never received a gradient: torch.optim.AdamW holds no state for it
+                state[i] = {"step": torch.tensor(float(steps)), "exp_avg": view(flat.m, k).clone(), "exp_avg_sq": view(flat.v, k).clone()}
         group = {"lr": self._lr_now(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "initial_lr": self.lr, "params": list(range(len(names)))}
@@ -249,12 +282,15 @@ class HotPathTrainer:
         return {r: q.cpu().to(torch.uint8) for r, q in enumerate(parts)}
 
     def save_checkpoint(self, path, **extra):
-        """All ranks call this (the generator states are gathered); only the leader (rank 0) writes the file."""
+        """All ranks call this (the generator states are gathered: the only collective); only the leader -- the first rank of
+        the group -- clones the state (4x the parameters on the device) and writes the file."""
+        rng = self.gather_rng_states()
+        if not self.is_leader:
+            return
         ckpt = self.state_dicts()
-        ckpt["rng"] = self.gather_rng_states()
+        ckpt["rng"] = rng
         ckpt.update(extra)
-        if self.rank == 0 or self.world == 1:
-            torch.save(ckpt, path)
+        torch.save(ckpt, path)
 
     def load_checkpoint(self, path_or_dict, map_location=None):
         """Reads a checkpoint written by the reference ``Trainer.save_checkpoint`` (or by ``save_checkpoint`` above):
@@ -275,18 +311,21 @@ class HotPathTrainer:
             opt = ckpt.get("optimizer")
             if opt is not None:
                 st = opt["state"]
-                assert len(st) in (0, len(names)), "optimizer state does not match the parameter list"
+                ncls = len(flat.cls_names)
+                assert len(st) in (0, len(names), len(names) - ncls), "optimizer state does not match the parameter list"
                 flat.m.zero_(); flat.v.zero_()
-                steps = set()
+                steps, csteps = set(), set()
                 for i, k in enumerate(names):
                     e = st.get(i, st.get(str(i)))
                     if e is None:
                         continue
                     view(flat.m, k).copy_(e["exp_avg"])
                     view(flat.v, k).copy_(e["exp_avg_sq"])
-                    steps.add(int(e["step"]))
-                assert len(steps) <= 1, "per-parameter step counts differ"
+                    (csteps if k in flat.cls_names else steps).add(int(e["step"]))
+                # (only the class-embedding tensors may lag: they are the one group a step can leave without a gradient)
+                assert len(steps) <= 1 and len(csteps) <= 1, "per-parameter step counts differ"
                 flat.step_count = steps.pop() if steps else 0
+                flat.cls_steps = csteps.pop() if csteps else 0
             ema = ckpt.get("ema")
             if ema is not None and flat.ema is not None:
                 shadow = strip(ema["shadow"])
@@ -300,6 +339,7 @@ class HotPathTrainer:
             sch = ckpt.get("scheduler")
             if sch is not None and opt is None:
                 flat.step_count = int(sch.get("last_epoch", flat.step_count))
+                flat.cls_steps = flat.step_count
         if ckpt.get("rng") is not None:
             if int(self.rank) in ckpt["rng"]:
                 self.generator.set_state(ckpt["rng"][int(self.rank)].cpu())
