@@ -11,8 +11,11 @@ behind zeros).  A "step" = one reference ``Trainer.step``: t/noise draw, q_sampl
 gradient mean over ranks (RCCL, bucketed, overlapped), global-norm clip, AdamW, LR warm-up, EMA.
 ``value`` = global_batch / step time, inputs resident in HBM, barrier + synchronize on both sides, MAX over ranks.
 
-Extra objects on the same JSON line: ``roofline`` (dominant kernel, live HIP-event timing), ``cpu_baseline`` (the CPU
-oracle on the host cores, rank 0 at N=1 only), ``sampling`` (DDIM-50 + CFG w=1 images/s, the second half of the metric).
+Extra objects on the same JSON line: ``roofline`` (dominant kernel, live HIP-event timing; ``achieved`` / ``frac`` count the MFMA
+FLOPs the kernel EXECUTES, so frac <= 1; the algorithmic rate of a Winograd kernel sits beside it), ``cpu_baseline`` (the CPU
+oracle on the host cores, rank 0 at N=1 only), ``sampling`` (DDIM-50 + CFG w=1 images/s, the second half of the metric),
+``multi_gpu`` (N > 1: backend, rank count, per-rank step times, exposed all-reduce time), ``secondary`` (BASELINE configs[3]:
+CelebA 64x64 train step + DDIM-50 CFG sampling + its own cpu_baseline).
 """
 import argparse
 import json
@@ -66,22 +69,27 @@ def usable_cpus(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(batch=16, budget_s=18.0):
+def cpu_baseline(wl="cifar10", batch=16, budget_s=18.0):
     """The CPU oracle (oracle/, proved equal to the reference by the golden fixtures) doing the same train step on the
-    host cores: bounded sample (batch 16; one warm-up step, then timed steps until ~budget_s of CPU
-    work), reported beside the GPU number, never the thing measured."""
+    host cores: bounded sample (one warm-up step, then timed steps until ~budget_s of CPU work),
+    reported beside the GPU number, never the thing measured."""
     from oracle import unet_ref, diffusion_ref as dref
     from oracle.unet_ref import param_shapes
+    W = WORKLOADS[wl]
+    cfg, res = W["cfg"], W["res"]
     ncpu = usable_cpus()
     torch.set_num_threads(ncpu)
     g = torch.Generator().manual_seed(0)
     sd = {}
-    for k, shp in param_shapes(CIFAR).items():
+    for k, shp in param_shapes(cfg).items():
         fan = max(int(torch.tensor(shp[1:]).prod()) if len(shp) > 1 else 1, 1)
         sd[k] = (torch.randn(shp, generator=g) * fan ** -0.5).requires_grad_(True)
-    x0 = torch.rand((batch, 3, 32, 32), generator=g) * 2 - 1
-    y = torch.randint(1, 11, (batch,), generator=g).float()
-    den = lambda a, b, c: unet_ref.unet_forward(sd, CIFAR, a, b, c, train=True)
+    x0 = torch.rand((batch, 3, res, res), generator=g) * 2 - 1
+    if cfg.get("multitags"):
+        y = (torch.rand((batch, cfg["num_classes"]), generator=g) < 0.2).float()
+    else:
+        y = torch.randint(1, cfg["num_classes"] + 1, (batch,), generator=g).float()
+    den = lambda a, b, c: unet_ref.unet_forward(sd, cfg, a, b, c, train=True)
     sched = dref.make_schedule("cosine")
     times, t_start = [], time.perf_counter()
     while True:                           # first pass warms the allocator / thread pool and is not counted
@@ -105,15 +113,19 @@ def cpu_baseline(batch=16, budget_s=18.0):
     except Exception:
         model_name = "unknown"
     return {"value": round(batch / med, 3), "unit": "images/s", "cores": ncpu, "kind": "port",
-            "sample": f"CIFAR-10 cond UNet train step (q_sample+fwd+v-loss+bwd, no optimizer), batch {batch}, "
+            "sample": f"{W['short']} train step (q_sample+fwd+v-loss+bwd, no optimizer), batch {batch}, "
                       f"median of {len(timed)} timed step(s) after {'1 warm-up' if len(times) > 1 else 'no warm-up (bounded)'}, "
                       f"torch CPU fp32 on {ncpu} threads, {model_name}"}
 
 
+# fwd_exec_frac: share of the ALGORITHMIC forward FLOPs the matrix cores execute.  The residual-block 3x3 convolutions run as
+# Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and channel pair where the convolution defines 36): conv3x3 FLOPs of
+# SURVEY 8 minus the thin in/out convolutions, x 4/9, plus everything else at 1.  CIFAR: (32.61 * 4/9 + 0.03 + 5.00) / 37.64;
+# CelebA: (183.71 * 4/9 + 0.09 + 17.50) / 201.3
 WORKLOADS = {
-    "cifar10": dict(cfg=CIFAR, res=32, fwd_gflop=FWD_GFLOP_PER_IMG,
+    "cifar10": dict(cfg=CIFAR, res=32, fwd_gflop=FWD_GFLOP_PER_IMG, fwd_exec_frac=0.5187, short="CIFAR-10 cond UNet",
                     name="CIFAR-10 32x32 class-cond v-pred UNet (cifar10_cond.json, 60.8M params)"),
-    "celeba": dict(cfg=CELEBA, res=64, fwd_gflop=CELEBA_FWD_GFLOP_PER_IMG,
+    "celeba": dict(cfg=CELEBA, res=64, fwd_gflop=CELEBA_FWD_GFLOP_PER_IMG, fwd_exec_frac=0.4930, short="CelebA 64x64 UNet (merged config)",
                    name="CelebA 64x64 multitag v-pred UNet (celeba.json+defaults.json, 266.8M params)"),
 }
 PEAK_HBM_TBS = 8.0                     # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured for a streaming copy)
@@ -121,12 +133,50 @@ PEAK_HBM_TBS = 8.0                     # MI355X_MICROARCH.md: HBM3E spec peak (6
 
 def traffic_table():
     """HBM bytes per launch from the committed PMC passes (profiles/parse_rocprof.py): newest round first"""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             return name, json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         except Exception:
             continue
     return None, {}
+
+
+def executed_share(kernel_name):
+    """MFMA FLOPs a kernel executes per ALGORITHMIC FLOP recorded for it (v_diffusion/_hip.py records 2*M*N*K of the op each
+    launch implements): Winograd F(2x2,3x3) kernels 4/9; the fused attention backward recomputes the logits in both of its
+    kernels and dP in the second (7 products for the 4 the op defines: 7/4); everything else 1"""
+    if kernel_name.startswith("wino_"):
+        return 4.0 / 9.0
+    if kernel_name.startswith("attn_bwd_"):
+        return 7.0 / 4.0
+    return 1.0
+
+
+def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, barrier):
+    """DDIM-T + classifier-free guidance over SB images per GPU (2*SB UNet rows per reverse step): images/s + roofline"""
+    model.eval()
+    lab = labels[:SB].clone()
+    diffusion.p_sample(model, (8, 3, RES, RES), label=lab[:8], device=device, seed=131071 + rank, use_ddim=True)   # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    out = diffusion.p_sample(model, (SB, 3, RES, RES), label=lab, device=device, seed=131071 + rank, use_ddim=True)
+    barrier()
+    ds = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([ds], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ds = float(tmax.item())
+    model.train()
+    alg = T * 2 * W["fwd_gflop"] * SB / ds / 1e3                      # algorithmic TFLOP/s (SURVEY 8d: 2 x T x forward)
+    exe = alg * W["fwd_exec_frac"]
+    return {"metric": f"ddim{T}_cfg_samples_per_sec", "value": round(world * SB / ds, 2), "unit": "images/s",
+            "seconds_per_batch": round(ds, 3), "batch_per_gpu": SB, "unet_rows_per_step": 2 * SB, "w_guide": float(diffusion.w_guide),
+            "roofline": {"bound": "mfma", "achieved": round(exe, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(exe / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic_tflops": round(alg, 2),
+                         "speedup_vs_direct_roofline": round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "note": "achieved = MFMA FLOPs executed (Winograd convolutions count 4/9 of their algorithmic FLOPs); "
+                                 "algorithmic_tflops = SURVEY 8d count of the direct convolution"},
+            "finite": bool(torch.isfinite(out).all())}
 
 
 def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_steps, extras=True):
@@ -167,15 +217,22 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = one_step()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0              # this rank's own time, before it waits for the slowest rank
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt_local / steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        mine = torch.tensor([rank_ms[0]], device=device, dtype=torch.float64)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        rank_ms = [float(q.item()) for q in parts]
     ms_per_step = dt / steps * 1e3
     res = dict(model=model, diffusion=diffusion, labels=labels, ms_per_step=ms_per_step, value=world * B * steps / dt,
-               final_loss=float(loss.item()), name=W["name"], res=RES, fwd_gflop=W["fwd_gflop"])
+               final_loss=float(loss.item()), name=W["name"], res=RES, fwd_gflop=W["fwd_gflop"], W=W, rank_ms=rank_ms)
 
     # ---- SURVEY 5 metric variants (rank-local, a few steps each): the reference loop's per-step host sync, and fwd+bwd alone
     if extras:
@@ -212,27 +269,39 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
         tname, tj = traffic_table()
         key = dom.split(" (+")[0]
         traffic = tj[key]["hbm_bytes_per_launch"] if key in tj else None
-        # Winograd F(2x2,3x3) kernels execute 16 MFMA multiplies per tile where the convolution defines 36: `achieved` stays the
-        # ALGORITHMIC rate (2*M*N*K of the direct convolution / time), which can exceed the fp32 MFMA peak;
-        # `mfma_executed_*` is what the matrix cores really ran
-        exe = 4.0 / 9.0 if dom.startswith("wino_") else 1.0
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / tt_ / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(fl / tt_ / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "mfma_executed_tflops": round(exe * fl / tt_ / 1e12, 2),
-                    "mfma_executed_frac": round(exe * fl / tt_ / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "note": ("Winograd F(2x2,3x3): algorithmic FLOPs = direct convolution; the kernel executes 4/9 of them on the matrix "
-                             "cores (exact fp32), so frac > mfma_executed_frac and may exceed 1") if exe < 1 else None,
+        # `achieved` / `frac` = what the matrix cores EXECUTE (<= peak by construction).  The Winograd kernels execute 4/9 of the
+        # algorithmic FLOPs of the convolution they implement (2*M*N*K of the direct form); that algorithmic rate is
+        # reported beside it as `algorithmic_tflops`, and its ratio to the peak as `speedup_vs_direct_roofline` (may exceed 1:
+        # it is a speed-up over the best possible direct-convolution kernel, not a utilisation)
+        exe = executed_share(dom)
+        alg_tf = fl / tt_ / 1e12
+        step_alg = sum(v[0] for v in agg.values()) / 2                      # algorithmic FLOPs of one step, as launched
+        step_exe = sum(v[0] * executed_share(k) for k, v in agg.items()) / 2
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(exe * alg_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(exe * alg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_tflops": round(alg_tf, 2),
+                    "speedup_vs_direct_roofline": round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "executed_share_of_algorithmic_flops": round(exe, 4),
+                    "note": ("Winograd F(2x2,3x3): the kernel executes 4/9 of the direct convolution's FLOPs on the matrix cores (exact "
+                             "fp32); achieved/frac count executed FLOPs, algorithmic_tflops the direct convolution's") if exe < 1 else None,
                     "traffic_note": f"HBM+fabric bytes per launch, PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/{tname}",
                     "clock_note": ("peak = 2.4 GHz figure; in-kernel s_memtime/s_memrealtime stamps show the shader clock at 1.75-1.9 GHz while the "
-                                   "Winograd convolution runs and 2.1 GHz under its weight gradient (DESIGN.md section 3, tests/probe/wino_phases.py)")
+                                   "Winograd convolution runs and 2.1 GHz under its weight gradient (DESIGN.md section 3, profiles/r03_wino_clock.txt)")
                                   if exe < 1 else None,
                     "launches_per_step": n // 2, "avg_launch_ms": round(tt_ / n * 1e3, 4),
-                    "flops_per_launch": round(fl / n / 1e9, 3), "flops_unit": "GFLOP (2*M*N*K of the implicit GEMM)",
+                    "flops_per_launch": round(exe * fl / n / 1e9, 3), "flops_unit": "GFLOP executed on the matrix cores per launch",
+                    "algorithmic_flops_per_launch": round(fl / n / 1e9, 3),
                     "share_of_matmul_time": round(tt_ / total_t, 3),
-                    "all_matmul_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / 2 * 1e3, 2),
-                                               "launches_per_step": v[2] // 2} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])},
-                    "step_matmul_tflops": round(3 * W["fwd_gflop"] * B / (ms_per_step * 1e-3) / 1e3, 2)}
-        if hbm:     # the dominant HBM-bound kernel class: algorithmic bytes (operands read + written once) / live time / 8 TB/s
+                    "all_matmul_kernels": {k: {"tflops": round(executed_share(k) * v[0] / v[1] / 1e12, 2),
+                                               "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / 2 * 1e3, 2),
+                                               "launches_per_step": v[2] // 2} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])
+                                           if v[0] > 0 or v[1] / 2 * 1e3 >= 0.05},
+                    "whole_step": {"mfma_executed_tflops": round(step_exe / (ms_per_step * 1e-3) / 1e12, 2),
+                                   "frac": round(step_exe / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "algorithmic_tflops": round(3 * W["fwd_gflop"] * B / (ms_per_step * 1e-3) / 1e3, 2),
+                                   "speedup_vs_direct_roofline": round(3 * W["fwd_gflop"] * B / (ms_per_step * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "launched_algorithmic_gflop_per_step": round(step_alg / 1e9, 1)}}
+        if hbm:     # the dominant HBM-bound kernel: algorithmic bytes (operands read + written once) / live time / 8 TB/s
             hd = max(hbm, key=lambda k: hbm[k][1])
             by, th, nh = hbm[hd]
             hk = hd[4:]
@@ -244,6 +313,34 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
                                "all_hbm_kernels": {k[4:]: {"gbs": round(v[0] / v[1] / 1e9, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3),
                                                            "launches_per_step": v[2] // 2} for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}}
     res["roofline"] = roofline
+
+    # ---- multi-GPU self-check (no 8-GPU node was available to the build: the first N > 1 run explains itself): the backend
+    # really in use and its rank count, per-rank step times, and how much of the gradient all-reduce is NOT hidden behind
+    # backward = step time with the bucketed all-reduce minus step time with the reducer switched off.  Run last: without the
+    # all-reduce the replicas' weights drift apart, which no later measurement depends on.
+    mg = None
+    if world > 1 or trainer.reducer.active:
+        n = max(3, min(steps, 5))
+        was = trainer.reducer.active
+        trainer.reducer.active = False
+        one_step(); barrier(); t0 = time.perf_counter()
+        for _ in range(n):
+            one_step()
+        barrier()
+        ms_off = (time.perf_counter() - t0) / n * 1e3
+        trainer.reducer.active = was
+        if world > 1:
+            tmax = torch.tensor([ms_off], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            ms_off = float(tmax.item())
+        mg = {"backend": dist.get_backend() if dist.is_initialized() else None,
+              "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
+              "devices_visible": torch.cuda.device_count(),
+              "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
+              "ms_per_step_no_allreduce": round(ms_off, 3), "allreduce_exposed_ms": round(ms_per_step - ms_off, 3),
+              "grad_bytes_per_step": 4 * trainer.flat.numel, "buckets": len(trainer.reducer.bounds),
+              "bucket_bytes": 4 * (trainer.reducer.bounds[0][1] - trainer.reducer.bounds[0][0])}
+    res["multi_gpu"] = mg
     res["trainer"] = trainer
     return res
 
@@ -296,29 +393,10 @@ def main():
     # ---- sampling: DDIM-50 + classifier-free guidance (w=1): 2B UNet rows per step
     sampling = None
     if not args.no_sample:
-        model.eval()
-        SB = B
-        lab = labels[:SB].clone()
-        diffusion.p_sample(model, (8, 3, RES, RES), label=lab[:8], device=device, seed=131071 + rank, use_ddim=True)   # warm-up
-        barrier()
-        t0 = time.perf_counter()
-        out = diffusion.p_sample(model, (SB, 3, RES, RES), label=lab, device=device, seed=131071 + rank, use_ddim=True)
-        barrier()
-        ds = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([ds], device=device, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            ds = float(tmax.item())
-        T = args.sample_steps
-        sampling = {"metric": f"ddim{T}_cfg_samples_per_sec", "value": round(world * SB / ds, 2), "unit": "images/s",
-                    "seconds_per_batch": round(ds, 3), "batch_per_gpu": SB, "unet_rows_per_step": 2 * SB, "w_guide": 1.0,
-                    "matmul_tflops": round(T * 2 * fwd_gflop * SB / ds / 1e3, 2),
-                    "frac_of_fp32_mfma_peak": round(T * 2 * fwd_gflop * SB / ds / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "finite": bool(torch.isfinite(out).all())}
-        model.train()
+        sampling = sample_once(diffusion, model, labels, B, RES, args.sample_steps, r["W"], device, rank, world, barrier)
 
-    # ---- secondary workload (BASELINE configs[3]): CelebA 64x64, per-GPU batch 128, train steps only -- short, so the default
-    # run stays within minutes; its sampling figure is `--config celeba`
+    # ---- secondary workload (BASELINE configs[3]): CelebA 64x64, per-GPU batch 128 -- a few train steps, then DDIM-50 + CFG
+    # sampling of 128 images (the second half of the north-star metric on CelebA-shaped tensors), then the CPU oracle beside it
     secondary = None
     if wl == "cifar10" and not args.no_secondary and B == 128:
         del model, diffusion
@@ -331,18 +409,25 @@ def main():
         rf = r2["roofline"]
         secondary = {"metric": "train_images_per_sec", "value": round(r2["value"], 2), "unit": "images/s", "steps": 5, "warmup": 2,
                      "ms_per_step": round(r2["ms_per_step"], 3),
-                     "config": {"workload": r2["name"] + " full train step (BASELINE configs[3])", "global_batch": world * 128,
-                                "per_gpu_batch": 128, "resolution": 64, "final_loss": round(r2["final_loss"], 5)},
-                     "frac_of_fp32_mfma_peak_whole_step": round(3 * r2["fwd_gflop"] * 128 / (r2["ms_per_step"] * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "config": {"workload": r2["name"] + " full train step (BASELINE configs[3]); second figure: DDIM-50 CFG w=1 sampling",
+                                "global_batch": world * 128, "per_gpu_batch": 128, "resolution": 64, "final_loss": round(r2["final_loss"], 5)},
                      "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
-                     "roofline": None if rf is None else {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
-                                                                              "launches_per_step", "avg_launch_ms", "flops_per_launch",
-                                                                              "share_of_matmul_time", "step_matmul_tflops")}}
+                     "roofline": None if rf is None else {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_tflops",
+                                                                              "speedup_vs_direct_roofline", "launches_per_step", "avg_launch_ms",
+                                                                              "flops_per_launch", "share_of_matmul_time", "whole_step")}}
         if rf is not None:
             top = sorted(rf["all_matmul_kernels"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:8]
             secondary["roofline"]["top_matmul_kernels"] = dict(top)
             if "hbm" in rf:
-                secondary["roofline"]["hbm"] = {k: rf["hbm"][k] for k in ("kernel", "achieved", "unit", "frac", "ms_per_step")}
+                secondary["roofline"]["hbm"] = {k: rf["hbm"][k] for k in ("kernel", "achieved", "unit", "frac", "traffic", "ms_per_step")}
+        if not args.no_sample:
+            r2.pop("trainer")
+            gc.collect()
+            torch.cuda.empty_cache()
+            secondary["sampling"] = sample_once(r2["diffusion"], r2["model"], r2["labels"], 128, 64, args.sample_steps, r2["W"], device,
+                                                rank, world, barrier)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            secondary["cpu_baseline"] = cpu_baseline("celeba", batch=4, budget_s=12.0)
         del r2
 
     cpu = None
@@ -357,10 +442,10 @@ def main():
                                        "second figure: DDIM-50 CFG w=1 sampling",
                            "global_batch": world * B, "per_gpu_batch": B, "resolution": RES, "parallelism": f"dp{world}",
                            "final_loss": round(r["final_loss"], 5)},
-                "frac_of_fp32_mfma_peak_whole_step": round(3 * fwd_gflop * B / (r["ms_per_step"] * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "ms_per_step_with_loss_item": r.get("ms_per_step_with_loss_item"), "ms_fwd_bwd_only": r.get("ms_fwd_bwd_only"),
                 "hbm_peak_gib": round(hbm_peak / 2 ** 30, 2),
-                "roofline": r["roofline"], "cpu_baseline": cpu, "sampling": sampling, "secondary": secondary}
+                "roofline": r["roofline"], "cpu_baseline": cpu, "sampling": sampling, "multi_gpu": r.get("multi_gpu"),
+                "secondary": secondary}
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -1,11 +1,24 @@
+"""PMC target (program directly after `rocprofv3 --pmc ... --`): the two dominant Winograd kernels of the CIFAR bs-128 train step at
+their bench launches -- wino_conv_wide_kernel<16, 640, true> (forward + GroupNorm partials, 256->256 @32x32) and
+wino_wgrad_kernel<16, true> -- 6 launches each, through the PRODUCT library."""
 import os, sys, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(ROOT, "v-diffusion-torch_amd"))
 from v_diffusion import _hip as H
-DEV="cuda"
-nimg,Hh,Ww,Cin,Cout=128,32,32,256,256
-x=torch.randn(nimg,Hh,Ww,Cin,device=DEV); w=torch.randn(Cout,Cin,3,3,device=DEV)*(9*Cin)**-0.5
-uf=torch.empty(16,Cout,Cin,device=DEV); H.wino_pack(w,Cout,Cin,uf=uf)
-y=torch.empty(nimg,Hh,Ww,Cout,device=DEV)
-for _ in range(4): H.conv3x3_wino(x,Cin,uf,None,y,Cout,nimg,Hh,Ww,Cin,Cout)
+DEV = "cuda"
+nimg, Hh, Ww, Cin, Cout = 128, 32, 32, 256, 256
+x = torch.nn.functional.silu(torch.randn(nimg, Hh, Ww, Cin, device=DEV))
+w = torch.randn(Cout, Cin, 3, 3, device=DEV) * (9 * Cin) ** -0.5
+b = torch.randn(Cout, device=DEV)
+res = torch.randn(nimg, Hh, Ww, Cout, device=DEV)
+dy = torch.randn(nimg, Hh, Ww, Cout, device=DEV) * 0.05
+uf = torch.empty(16, Cout, Cin, device=DEV)
+H.wino_pack(w, Cout, Cin, uf=uf)
+y = torch.empty(nimg, Hh, Ww, Cout, device=DEV)
+part = torch.empty(H.stats_part_numel(nimg, Hh * Ww, Cout), device=DEV)
+dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
+db = torch.empty(Cout, device=DEV)
+for _ in range(6):
+    H.conv3x3_wino(x, Cin, uf, b, y, Cout, nimg, Hh, Ww, Cin, Cout, res=res, ldres=Cout, stats_part=part)
+    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
 torch.cuda.synchronize()

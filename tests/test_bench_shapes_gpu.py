@@ -300,7 +300,7 @@ def test_wino_wgrad_at_bench_launches(H, case):
     tws, slabs, dbias = k // 2000, (k // 2) % 1000, k & 1
     assert (tws, dbias) == (min(Ww // 2, 16), 1) and slabs >= 1, (tws, slabs, dbias)
     blocks = ((Cout + 63) // 64) * ((Cin + 63) // 64)
-    assert blocks * slabs >= NCU, f"{blocks} blocks x {slabs} slabs leave CUs idle"
+    assert blocks * slabs >= 0.9 * NCU, f"{blocks} blocks x {slabs} slabs leave more than a tenth of the CUs idle"
     assert H.lib().vd_gemm_last_tile() == tile_before, "the Winograd weight gradient must not touch vd_gemm_last_tile"
     dw2 = torch.empty_like(dw)
     H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=None)

@@ -504,8 +504,11 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     }
 }
 
+thread_local int g_last_gn_bwd = 0;   // NPT * 10000 + TPB of the last fused launch, -1 = two-pass form, 0 = no norm (plain resample)
+
 template <int TPB>
 void launch_fused_bwd(int npt, dim3 grid, hipStream_t st, const FusedBwdArgs& f) {
+    g_last_gn_bwd = (npt <= 1 ? 1 : (npt <= 2 ? 2 : (npt <= 4 ? 4 : 8))) * 10000 + TPB;
     if (npt <= 1) hipLaunchKernelGGL((gn_bwd_fused_kernel<1, TPB>), grid, dim3(TPB), 0, st, f);
     else if (npt <= 2) hipLaunchKernelGGL((gn_bwd_fused_kernel<2, TPB>), grid, dim3(TPB), 0, st, f);
     else if (npt <= 4) hipLaunchKernelGGL((gn_bwd_fused_kernel<4, TPB>), grid, dim3(TPB), 0, st, f);
@@ -637,6 +640,7 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
     p.resample = resample; p.has_norm = has_norm; p.H = H; p.W = W; p.HW = HW; p.C = C; p.nimg = nimg;
     p.chunks = (int)((HW + PPC - 1) / PPC);
     a.add = add; a.ldadd = ldadd; a.dx = dx; a.lddx = lddx; a.accumulate_dx = accumulate_dx;
+    g_last_gn_bwd = has_norm ? -1 : 0;
     if (has_norm) {
         VD_REQUIRE(x && coef && beta && dgamma && dbeta && C % G == 0 && ldx % 4 == 0, "vd_gn_apply_bwd: missing norm operands");
         VD_REQUIRE(!film || dfilm, "vd_gn_apply_bwd: film given without dfilm");
@@ -685,6 +689,8 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
     VD_LAUNCH_CHECK("gn_bwd_apply_kernel");
     return 0;
 }
+
+extern "C" int vd_gn_bwd_last_kernel(void) { return g_last_gn_bwd; }
 
 extern "C" size_t vd_colsum_ws_bytes(int64_t M, int32_t N) {
     return (size_t)(((M + PPC - 1) / PPC) * 2 * N) * sizeof(float);

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "vd_gn_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vd_gn_apply_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _vp, _i64, _i32,
                                   _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_gn_bwd_last_kernel": (C.c_int, []),
     "vd_colsum_ws_bytes": (_sz, [_i64, _i32]),
     "vd_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "vd_axpby": (C.c_int, [_vp, _i64, _f32, _vp, _i64, _f32, _i64, _i32, _vp]),
@@ -351,10 +352,11 @@ def gn_stats(x, ldx, nimg, HW, Cc, stats, G=32, eps=1e-6):
 
 
 class _TimedBytes:
-    """PROFILE record of an HBM-bound launch: ("hbm:<name>", algorithmic bytes = operands read + written once, events)"""
+    """PROFILE record of an HBM-bound launch: ("hbm:<rocprof kernel name>", algorithmic bytes = operands read + written once,
+    events).  ``rename`` (optional) is called after the launch and returns the name of the instantiation that ran."""
 
-    def __init__(self, name, nbytes):
-        self.name, self.nbytes = name, nbytes
+    def __init__(self, name, nbytes, rename=None):
+        self.name, self.nbytes, self.rename = name, nbytes, rename
 
     def __enter__(self):
         if PROFILE is not None:
@@ -365,12 +367,19 @@ class _TimedBytes:
     def __exit__(self, *exc):
         if PROFILE is not None and exc[0] is None:
             self.e1.record()
-            PROFILE.append(("hbm:" + self.name, float(self.nbytes), self.e0, self.e1))
+            PROFILE.append(("hbm:" + (self.rename() if self.rename else self.name), float(self.nbytes), self.e0, self.e1))
+
+
+def _gn_bwd_name():
+    k = lib().vd_gn_bwd_last_kernel()
+    if k > 0:
+        return f"gn_bwd_fused_kernel<{k // 10000}, {k % 10000}>"
+    return "gn_bwd_apply_kernel (two-pass form)" if k < 0 else "gn_bwd_apply_kernel (resample)"
 
 
 def gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G=32):
     hw_out = H * W // 4 if resample == RS_DOWN else (H * W * 4 if resample == RS_UP else H * W)
-    with _TimedBytes("gn_apply" if gamma is not None else "resample", 4.0 * nimg * Cc * (H * W + hw_out)):
+    with _TimedBytes("gn_apply_kernel" if gamma is not None else "gn_apply_kernel (resample)", 4.0 * nimg * Cc * (H * W + hw_out)):
         _gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G)
 
 
@@ -385,7 +394,7 @@ def gn_apply_bwd(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, r
     ws = workspace(nb, dy.device, "gn")
     hw_dy = H * W // 4 if resample == RS_DOWN else (H * W * 4 if resample == RS_UP else H * W)
     nbytes = 4.0 * nimg * Cc * (hw_dy + H * W * (1 + (gamma is not None) + (add is not None) + bool(accumulate_dx)))
-    with _TimedBytes("gn_apply_bwd" if gamma is not None else "resample_bwd", nbytes):
+    with _TimedBytes("gn_apply_bwd", nbytes, rename=_gn_bwd_name):
         _gn_apply_bwd_call(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
                            accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G, ws)
 
