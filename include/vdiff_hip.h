@@ -119,6 +119,23 @@ int vd_wino_wgrad_last_kernel(void);
 int vd_wino_set_probe(unsigned long long* buf);
 #endif
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
+/* ---- input gradient of the same convolution as Winograd F(4x4, 3x3) (csrc/wino43.hip): 36 multiplies per 4x4 output tile where
+ * F(2x2,3x3) needs 64 -- 1.78x fewer matrix-core cycles, ~7x the rounding error of a direct fp32 sum, which is why it serves
+ * gradients only (stated bound: per-tensor relative L2 <= 1e-4) and never the forward pass (autograd of modules.py:141-144).
+ *   U43 = vd_wino43_pack(w): (G rot180(w[co][ci]) G^T)[36] in the order the kernel's lanes read it, vd_wino43_u_floats(Cout, Cin) floats;
+ *   dx[nimg][H][W][:Cin] = vd_conv3x3_dgrad_wino43(dy[nimg][H][W][:Cout], U43)   every element written, no accumulation.
+ * _supported: 1 for 32x32 images and 64-wide images with H % 16 == 0, Cout % 8 == 0, Cin % 32 == 0, 16-byte rows, tensors < 2 GiB;
+ * otherwise call vd_conv3x3_wino with the rotated F(2x2,3x3) image.  vd_wino43_last_kernel: tiles per row (8 / 16) of the calling
+ * thread's last launch = the instantiation wino43_dgrad_kernel<TWT> (profiling / test aid). */
+int vd_conv3x3_dgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t lddy, int64_t lddx);
+size_t vd_wino43_u_floats(int32_t Cout, int32_t Cin);
+int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const float* U43, float* dx, int64_t lddx, int32_t nimg, int32_t H, int32_t W,
+                            int32_t Cin, int32_t Cout, void* stream);
+int vd_wino43_last_kernel(void);
+int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, void* stream);
+/* all tensors in one launch: items_dev = [n][8] int64 {w, U43, 0, Cout, Cin, 0, 0, first block}; a tensor takes (Cin/32)*(Cout/8) blocks */
+int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
+
 /* all 3x3 kernels of a network in one launch: items_dev = [n][8] int64 {w, uf, ud, Cout, Cin, tiled, 0, first 256-thread block};
  * tiled = 1 (Cout, Cin multiples of 16): the tensor takes (Cout/16)*(Cin/16) blocks of one 16x16 tile, else ceil(Cout*Cin/256) */
 int vd_wino_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);

@@ -3,6 +3,7 @@
 
     python profiles/parse_rocprof.py stats   <kernel_stats.csv>  <out.csv>  [steps]
     python profiles/parse_rocprof.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python profiles/parse_rocprof.py pmc     <out.json> <counter_collection.csv> [<counter_collection.csv> ...]
 
 `traffic` follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from separate --pmc passes, both are in
 KiB, and on gfx950 FETCH_SIZE under-reports wide coalesced reads by exactly 2x, so bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.
@@ -51,8 +52,35 @@ def traffic(fetch_csv, write_csv, dst):
                "kernels": out}, open(dst, "w"), indent=1)
 
 
+def pmc(dst, *srcs):
+    """per-kernel averages of every counter of one or more `--pmc` passes (counter_collection.csv): {kernel: {counter: mean per launch}}.
+    rocprofv3 sums a counter over its hardware instances (SQ: all SEs/XCDs; GRBM_GUI_ACTIVE: the 8 XCDs)."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in srcs:
+        per_dispatch = collections.defaultdict(float)
+        names = {}
+        for r in csv.DictReader(open(path)):
+            key = (path, r["Dispatch_Id"], r["Counter_Name"])
+            per_dispatch[key] += float(r["Counter_Value"])
+            names[(path, r["Dispatch_Id"])] = short(r["Kernel_Name"])
+            per_dispatch[(path, r["Dispatch_Id"], "duration_us")] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+        for (pth, disp, ctr), v in per_dispatch.items():
+            agg[names[(pth, disp)]][ctr].append(v)
+    out = {k: dict(launches=max(len(v) for v in c.values()), **{ctr: round(sum(v) / len(v), 1) for ctr, v in sorted(c.items())})
+           for k, c in agg.items()}
+    for k, c in out.items():      # derived: effective clock (MI355X_MICROARCH.md, DVFS give-back) and MFMA-pipe busy share of all SIMD cycles
+        if c.get("GRBM_GUI_ACTIVE") and c.get("duration_us"):
+            c["derived_clock_mhz"] = round(c["GRBM_GUI_ACTIVE"] / 8 / c["duration_us"], 1)
+            if c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                c["derived_mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)
+    json.dump({"method": "rocprofv3 --pmc <counters> (own passes, no tracing); per-launch mean of each counter summed over its hardware instances",
+               "kernels": out}, open(dst, "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+    elif sys.argv[1] == "pmc":
+        pmc(sys.argv[2], *sys.argv[3:])
     else:
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])

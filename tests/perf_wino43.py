@@ -1,0 +1,57 @@
+"""Same-box A/B of the two input-gradient kernels (not a test): Winograd F(4x4,3x3) (csrc/wino43.hip) against F(2x2,3x3) (wino.hip) at
+the benchmark's layer shapes, plus the error of each against fp64.   python tests/perf_wino43.py"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "v-diffusion-torch_amd"))
+from v_diffusion import _hip as H
+
+DEV = "cuda"
+
+
+def timeit(fn, n=12):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def conv_fp64(x, w):
+    B, Hh, Ww, Cin = x.shape
+    xp = F.pad(x.double(), (0, 0, 1, 1, 1, 1))
+    out = torch.zeros(B, Hh, Ww, w.shape[0], dtype=torch.float64, device=DEV)
+    for ky in range(3):
+        for kx in range(3):
+            out += xp[:, ky:ky + Hh, kx:kx + Ww, :] @ w[:, :, ky, kx].double().T
+    return out
+
+
+for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256), (128, 64, 64, 192, 192), (128, 32, 32, 384, 384)):
+    g = torch.Generator(DEV).manual_seed(1)
+    dy = torch.randn((nimg, Hh, Ww, Cout), device=DEV, generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * (9 * Cin) ** -0.5
+    ud = torch.empty(16, Cin, Cout, device=DEV)
+    H.wino_pack(w, Cout, Cin, ud=ud)
+    u43 = torch.empty(H.lib().vd_wino43_u_floats(Cout, Cin), device=DEV)
+    H.wino43_pack(w, Cout, Cin, u43)
+    dx2, dx4 = torch.empty(nimg, Hh, Ww, Cin, device=DEV), torch.full((nimg, Hh, Ww, Cin), 7.0, device=DEV)
+    f2 = lambda: H.conv3x3_wino(dy, Cout, ud, None, dx2, Cin, nimg, Hh, Ww, Cout, Cin)
+    f4 = lambda: H.conv3x3_dgrad_wino43(dy, Cout, u43, dx4, Cin, nimg, Hh, Ww, Cin, Cout)
+    t2, t4 = timeit(f2), timeit(f4)
+    ref = conv_fp64(dy, w.flip(2, 3).transpose(0, 1).contiguous())
+    sc = ref.abs().max().item()
+    e2, e4 = (dx2.double() - ref).abs().max().item(), (dx4.double() - ref).abs().max().item()
+    r2, r4 = ((dx2.double() - ref).norm() / ref.norm()).item(), ((dx4.double() - ref).norm() / ref.norm()).item()
+    fl = 2.0 * nimg * Hh * Ww * Cout * 9 * Cin
+    print(f"{nimg}x{Hh}x{Ww} {Cout}->{Cin}: F(2,3) {t2:.3f} ms ({fl / t2 / 1e9:.0f} alg TF) err {e2:.2e} rel-L2 {r2:.2e} | "
+          f"F(4,3) {t4:.3f} ms ({fl / t4 / 1e9:.0f} alg TF, {fl / 4 / t4 / 1e9:.0f} exe) err {e4:.2e} rel-L2 {r4:.2e} | scale {sc:.1f} | x{t2 / t4:.2f}")

@@ -1,0 +1,385 @@
+// wino43.hip -- INPUT GRADIENT of the 3x3 / stride 1 / pad 1 convolution as Winograd F(4x4, 3x3) on the fp32 matrix cores, NHWC.
+// Reference op: autograd of modules.Conv2d -> F.conv2d (modules.py:141-144 <- unet.py:121,125) with respect to its input.
+//
+// Why a second Winograd order, and why only for gradients: F(4x4,3x3) needs 36 multiplies per 4x4 output tile and (ci, co) pair
+// where F(2x2,3x3) (wino.hip) needs 16 per 2x2 tile -- 2.25 instead of 4 per output, 1.78x fewer matrix-core cycles again -- at
+// ~7x the rounding error of a direct fp32 sum (measured against fp64: tests).  That is too coarse for the forward pass (stated
+// bound 2e-5 on the UNet output) and an order of magnitude inside the 1e-4 relative bound on gradients, so the forward
+// convolutions stay on F(2x2,3x3) and this kernel serves the input gradients of the layers whose geometry it covers.
+//
+//   U[xi][n][k]   = (G rot180(w[k][n]) G^T)[xi]        xi = 6a+b in 0..35, n = conv input channel (GEMM column), k = conv output
+//                                                     channel (GEMM K)                            (vd_wino43_pack*, per weight update)
+//   V[xi][t][k]   = (B^T d[t][k] B)[xi]                d = 6x6 patch of dy around 4x4-output tile t               (on the fly)
+//   M[xi][t][n]   = sum_k V[xi][t][k] U[xi][n][k]      36 independent GEMMs                                        (MFMA)
+//   dx[t][u][v][n] = (A^T M[.][t][n] A)[u][v]                                                                      (epilogue)
+//
+// Work item = 64 tiles (a 32x32 image, or 16 pixel rows of a 64-wide one) x 32 channels x all 36 xi; persistent workgroups of 8
+// waves (two per SIMD, <= 256 registers), one per CU (156-160 KB of LDS):
+//   * wave w owns tile group w & 3 (16 tiles) and HALF of xi: rows a in {3h .. 3h+2}, h = w >> 2, all six b -- 18 xi x 2 channel
+//     blocks = 144 accumulator registers.  Splitting xi by rows splits the input transform cleanly: the row pass of half h needs
+//     five of the six patch rows and half of the arithmetic, the column pass is per row.  The two halves of a tile group meet
+//     once per item, in the epilogue, through LDS (the stages are dead by then).
+//   * K tile = 8 channels (two 16-byte granules per pixel): a lane feeds channels {2 kq, 2 kq + 1} (kq = lane >> 4 = the k slot of
+//     v_mfma_f32_16x16x4_f32) as two MFMA k-steps.  Per K tile the raw patch image (not V) and the 36 U tiles go HBM/L2 -> LDS with
+//     `buffer_load_dwordx4 ... lds`; two stages, the DMA of tile t+1 is issued between the MFMA steps of tile t, one barrier per tile.
+//   * patch image: [granule][pixel row][4 runs of columns x == r (mod 4)][slot] 16-byte slots, so that the 16 tiles of a wave (4
+//     pixels apart) read consecutive slots; the row pitch is chosen so that tiles of different tile rows fall on different banks
+//     (conflict-free ds_read_b64 for 8 or 16 tiles per row).
+//   * U image: packed by vd_wino43_pack in exactly the order the lanes read it -- [32-channel block][K tile][xi][n][kq][cb][j] -- so
+//     (lane 16 kq + n of the MFMA row operand owns floats 4 lane .. 4 lane + 3) a stage is ONE contiguous 36 KB run of global
+//     memory (36 linear DMA pieces) and a lane's fragment for both 16-channel blocks
+//     and both k-steps is one conflict-free ds_read_b128.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB = 0x80000000u;
+constexpr int KT = 8;                         // channels per K tile
+constexpr int TN = 32;                        // output channels per work item
+constexpr int TILES = 64;                     // 4x4-output tiles per work item
+constexpr int U_STAGE = 36 * 4 * 16 * 2 * 2;  // floats of U per stage (36 KB): [xi][kq][n][cb][j] (lane = 16 kq + n reads 16 bytes)
+constexpr int THREADS = 512;
+
+struct Args43 {
+    const float* x; long long ldx;            // GEMM A side: dy  [nimg][H][W][>= K]
+    const float* U;                           // packed [N/32][K/8][36][4 kq][16 n][2 cb][2 j]
+    float* y; long long ldy;                  // dx      [nimg][H][W][>= N]
+    int nimg, H, W, K, N;
+    int items_per_img;                        // 1 (32x32) or H/16 (64 wide)
+    int ncb, nitems;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
+}
+
+// 1-D input transform B^T of F(4,3), rows {0,1,2} (HALF = 0) or {3,4,5} (HALF = 1), on two channels at once.
+//   B^T = [4 0 -5 0 1 0 ; 0 -4 -4 1 1 0 ; 0 4 -4 -1 1 0 ; 0 -2 -1 2 1 0 ; 0 2 -1 -2 1 0 ; 0 4 0 -5 0 1]
+template <int HALF>
+__device__ __forceinline__ void bt_half(const f32x2 (&d)[6], f32x2& o0, f32x2& o1, f32x2& o2) {
+    if (HALF == 0) {
+        const f32x2 t = d[4] - 4.f * d[2], u = d[3] - 4.f * d[1];
+        o0 = 4.f * d[0] + (d[4] - 5.f * d[2]);
+        o1 = t + u;
+        o2 = t - u;
+    } else {
+        const f32x2 c = d[4] - d[2], e = d[3] - d[1];
+        o0 = c + 2.f * e;
+        o1 = c - 2.f * e;
+        o2 = 4.f * d[1] + (d[5] - 5.f * d[3]);
+    }
+}
+// all six outputs (the column pass)
+__device__ __forceinline__ void bt_full(const f32x2 (&r)[6], f32x2 (&v)[6]) {
+    const f32x2 t = r[4] - 4.f * r[2], u = r[3] - 4.f * r[1], c = r[4] - r[2], e = r[3] - r[1];
+    v[0] = 4.f * r[0] + (r[4] - 5.f * r[2]);
+    v[1] = t + u;
+    v[2] = t - u;
+    v[3] = c + 2.f * e;
+    v[4] = c - 2.f * e;
+    v[5] = 4.f * r[1] + (r[5] - 5.f * r[3]);
+}
+
+// TWT = tiles per image row (8: 32-wide images, 16: 64-wide images)
+template <int TWT>
+__global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
+    constexpr int RUN = TWT + 1;                           // slots of one column class in a pixel row
+    constexpr int RP = 4 * RUN + ((TWT / 4) & 3);          // pixel-row pitch in slots: 4 * RP * 16 B == TWT * 16 B (mod 256 B)
+    constexpr int NTR = TILES / TWT;                       // tile rows per item (8 or 4)
+    constexpr int RIN = 4 * NTR + 2;                       // pixel rows held per item
+    constexpr int NS = RIN * RP;                           // patch slots per granule
+    constexpr int NPG = (NS + 63) / 64;                    // DMA pieces (1 KiB) per granule
+    constexpr int A_STAGE = 2 * NPG * 256;                 // floats
+    constexpr int STAGE = A_STAGE + U_STAGE;
+    constexpr int LGT = TWT == 8 ? 3 : 4;
+    static_assert(2 * STAGE * 4 <= 163840, "stages exceed the LDS");
+    static_assert(8 * 16 * 64 * 16 <= 2 * STAGE * 4, "epilogue exchange area exceeds the stages");
+    __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int tg = wave & 3;
+    const int nkt = p.K / KT;
+    const int G = gridDim.x;
+
+    // ---- DMA plan of this wave.  Patch pieces: granule wave & 1, slot groups (wave >> 1) + 4 j; U pieces wave + 8 j (linear copy).
+    constexpr int APL = (NPG + 3) / 4;
+    unsigned pxo[APL];
+    auto offsets = [&](int item) {
+        const int img = item / (p.ncb * p.items_per_img) * 1;   // (item = (img * items_per_img + part) * ncb + cb)
+        const int rem = item - img * (p.ncb * p.items_per_img);
+        const int part = rem / p.ncb;
+        const int y_first = 4 * NTR * part - 1;
+#pragma unroll
+        for (int j = 0; j < APL; ++j) {
+            const int s = (wave >> 1) + 4 * j;
+            const int slot = s * 64 + lane;
+            const int r = slot / RP, cs = slot - r * RP;
+            const int c = cs / RUN, idx = cs - c * RUN;
+            const int xx = 4 * idx + c - 1, yy = y_first + r;
+            unsigned vo = OOB;
+            if (s < NPG && r < RIN && cs < 4 * RUN && (unsigned)xx < (unsigned)p.W && (unsigned)yy < (unsigned)p.H)
+                vo = (unsigned)(((img * p.H + yy) * p.W + xx) * (int)p.ldx) * 4u;
+            pxo[j] = vo;
+        }
+    };
+    // piece i of this wave for K tile kt of channel block cb into stage st: i < 5: U piece wave + 8 i; else patch piece
+    auto issue_piece = [&](int i, int kt, int st, int cb) {
+        float* sb = smem + st * STAGE;
+        if (i < 5) {
+            const int q = wave + 8 * i;
+            if (q < 36) {
+                const float* src = p.U + ((long long)cb * nkt + kt) * U_STAGE;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(src);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sb + A_STAGE + q * 256), 16, lane * 16, q * 1024, 0, 0);
+            }
+        } else {
+            const int j = i - 5;
+            const int s = (wave >> 1) + 4 * j, g = wave & 1;
+            if (s < NPG) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sb + (g * NPG + s) * 256), 16, (int)pxo[j], g * 16, 0, 0);
+            }
+        }
+    };
+    constexpr int NPIECE = 5 + APL;
+
+    // ---- LDS read addresses (floats): patch position (pr, q) of this lane's tile, channels {2 lq, 2 lq + 1}
+    const int tl = 16 * tg + li;
+    const int tyl = tl >> LGT, tx = tl & (TWT - 1);
+    const int pbase = ((lq >> 1) * NPG * 64 + 4 * tyl * RP + tx) * 4 + (lq & 1) * 2;
+    auto poff = [](int pr, int q) { return (pr * RP + (q & 3) * RUN + (q >> 2)) * 4; };
+    const int uoff = A_STAGE + lane * 4;
+
+    auto run = [&](auto Hc) {
+        constexpr int HALF = decltype(Hc)::value;
+        for (int item = blockIdx.x; item < p.nitems; item += G) {
+            const int cb = item % p.ncb;
+            offsets(item);
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) issue_piece(i, 0, 0, cb);
+            f32x4 acc[18][2];
+#pragma unroll
+            for (int x = 0; x < 18; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int st = kt & 1;
+                const float* sa = smem + st * STAGE + pbase;
+                const float* su = smem + st * STAGE + uoff;
+                const bool dma = kt + 1 < nkt;
+                // row pass: R[a'][q] = sum_p B^T[3 HALF + a'][p] d[p][q]  (five of the six patch rows)
+                f32x2 R[3][6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    f32x2 d[6];
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr) {
+                        if ((HALF == 0 && pr == 5) || (HALF == 1 && pr == 0)) d[pr] = f32x2{0.f, 0.f};
+                        else d[pr] = *reinterpret_cast<const f32x2*>(sa + poff(pr, q));
+                    }
+                    bt_half<HALF>(d, R[0][q], R[1][q], R[2][q]);
+                }
+                f32x4 uf[2];
+                uf[0] = *reinterpret_cast<const f32x4*>(su + (18 * HALF) * 256);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    f32x2 V[6];
+                    bt_full(R[a], V);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        const int xl = 6 * a + b;
+                        if (xl < 17) uf[(xl + 1) & 1] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + 1) * 256);
+                        if (dma && xl < NPIECE) issue_piece(xl, kt + 1, st ^ 1, cb);
+                        const f32x4 u = uf[xl & 1];
+                        acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], V[b][0], acc[xl][0], 0, 0, 0);
+                        acc[xl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], V[b][0], acc[xl][1], 0, 0, 0);
+                        acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], V[b][1], acc[xl][0], 0, 0, 0);
+                        acc[xl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3], V[b][1], acc[xl][1], 0, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+
+            // ---------------- epilogue: dx = A^T M A      A^T = [1 1 1 1 1 0 ; 0 1 -1 2 -2 0 ; 0 1 1 4 4 0 ; 0 1 -1 8 -8 1]
+            // this wave holds rows a = 3 HALF + a' of M for both channel blocks: column pass in registers, then its partial row
+            // pass PT[u][v]; it hands the channel block it does not finish (1 - HALF) to its partner wave through LDS and
+            // finishes block HALF.  lane (li, lq): tile tl, channels 32 cb + 16 blk + 4 lq .. +3
+            f32x4* xch = reinterpret_cast<f32x4*>(smem);            // [wave][k = 4u+v][lane]; the stages are dead (last barrier)
+            f32x4 Y[4][4];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int blk = pass == 0 ? 1 - HALF : HALF;        // first the block that is given away
+                f32x4 S[3][4];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const f32x4 m0 = acc[6 * a][blk], m1 = acc[6 * a + 1][blk], m2 = acc[6 * a + 2][blk], m3 = acc[6 * a + 3][blk],
+                                m4 = acc[6 * a + 4][blk], m5 = acc[6 * a + 5][blk];
+                    const f32x4 p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4;
+                    S[a][0] = m0 + p12 + p34;
+                    S[a][1] = q12 + 2.f * q34;
+                    S[a][2] = p12 + 4.f * p34;
+                    S[a][3] = q12 + 8.f * q34 + m5;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (HALF == 0) {            // rows a = 0, 1, 2
+                        const f32x4 s12 = S[1][v] + S[2][v], d12 = S[1][v] - S[2][v];
+                        Y[0][v] = S[0][v] + s12; Y[1][v] = d12; Y[2][v] = s12; Y[3][v] = d12;
+                    } else {                    // rows a = 3, 4, 5
+                        const f32x4 s34 = S[0][v] + S[1][v], d34 = S[0][v] - S[1][v];
+                        Y[0][v] = s34; Y[1][v] = 2.f * d34; Y[2][v] = 4.f * s34; Y[3][v] = 8.f * d34 + S[2][v];
+                    }
+                }
+                if (pass == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) xch[(wave * 16 + 4 * u + v) * 64 + lane] = Y[u][v];
+                    __syncthreads();
+                }
+            }
+            {
+                const int partner = wave ^ 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Y[u][v] += xch[(partner * 16 + 4 * u + v) * 64 + lane];
+            }
+            {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const int img = item / (p.ncb * p.items_per_img);
+                const int part = (item - img * (p.ncb * p.items_per_img)) / p.ncb;
+                const int n0 = cb * TN + 16 * HALF + 4 * lq;
+                const int y0 = 4 * (NTR * part + tyl), x0 = 4 * tx;
+                const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
+                const unsigned ldy_u = (unsigned)p.ldy;
+                const unsigned pix00 = (unsigned)((img * p.H + y0) * p.W + x0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const unsigned vo = ((pix00 + (unsigned)(u * p.W + v)) * ldy_u + (unsigned)n0) * 4u;
+                        const f32x4 val = Y[u][v];
+                        const u32x4 wv = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(wv, yrs, (int)vo, 0, 0);
+                    }
+            }
+            __syncthreads();                                        // the exchange area is read: the next item's DMA may overwrite it
+        }
+    };
+    if ((wave >> 2) == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+// ---- weight transform for the input gradient: U[xi][n = ci][k = co] = (G rot180(w[co][ci]) G^T)[xi] in the packed order
+// [n / 32][k / 8][xi][(k % 8) / 2][n % 16][(n % 32) / 16][k % 2].   G = [1/4 0 0 ; -1/6 -1/6 -1/6 ; -1/6 1/6 -1/6 ; 1/24 1/12 1/6 ; 1/24 -1/12 1/6 ; 0 0 1]
+// One 256-thread block per (32 n, 8 k) tile: thread t IS position t of the tile's [kq][n][cb][j] order, so every xi is one
+// coalesced 1 KB run (thread 16 kq + n's four floats are what MFMA lane 16 kq + n reads with one ds_read_b128).  The transform is evaluated in fp64 and rounded once (its coefficients are not dyadic).
+__device__ __forceinline__ void pack43_tile(const float* w, float* U, int Cout, int Cin, int tile) {
+    const int nkt = Cout / KT;
+    const int nb = tile / nkt, kt = tile - nb * nkt;
+    const int t = threadIdx.x;
+    const int kq = t >> 6, n = (t >> 2) & 15, cbk = (t >> 1) & 1, j = t & 1;
+    const int ci = nb * 32 + 16 * cbk + n, co = kt * KT + 2 * kq + j;
+    const float* src = w + ((long long)co * Cin + ci) * 9;
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = (double)src[(2 - a) * 3 + (2 - b)];          // rot180
+    const double Gm[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    double tmp[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tmp[a][c] = Gm[a][0] * g[0][c] + Gm[a][1] * g[1][c] + Gm[a][2] * g[2][c];
+    float* dst = U + ((long long)nb * nkt + kt) * U_STAGE + t;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+            dst[(6 * a + b) * 256] = (float)(tmp[a][0] * Gm[b][0] + tmp[a][1] * Gm[b][1] + tmp[a][2] * Gm[b][2]);
+}
+
+__global__ __launch_bounds__(256) void wino43_pack_kernel(const float* w, float* U, int Cout, int Cin) {
+    pack43_tile(w, U, Cout, Cin, blockIdx.x);
+}
+
+// all tensors of a network in one launch; items: 8 x int64 per tensor {w, U, -, Cout, Cin, -, -, first block}
+__global__ __launch_bounds__(256) void wino43_pack_batched_kernel(const long long* items, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[8 * mid + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* it = items + 8 * lo;
+    pack43_tile(reinterpret_cast<const float*>(it[0]), reinterpret_cast<float*>(it[1]), (int)it[3], (int)it[4],
+                (int)((long long)blockIdx.x - it[7]));
+}
+
+thread_local int g_last43 = 0;
+
+}  // namespace
+
+/* 1 when vd_conv3x3_dgrad_wino43 serves the geometry: 32x32 images or 64-wide images with H % 16 == 0, Cout % 8 == 0 (GEMM K),
+ * Cin % 32 == 0 (output channels), 16-byte aligned rows, tensors below 2 GiB */
+extern "C" int vd_conv3x3_dgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t lddy, int64_t lddx) {
+    if (nimg <= 0 || Cout % KT || Cin % TN || lddy % 4 || lddx % 4) return 0;
+    if (!((W == 32 && H == 32) || (W == 64 && H % 16 == 0 && H >= 16))) return 0;
+    const long long px = (long long)nimg * H * W, lim = 0x7FFFFFF0LL / 4;
+    if (px * lddy >= lim || px * lddx >= lim) return 0;
+    return 1;
+}
+
+extern "C" size_t vd_wino43_u_floats(int32_t Cout, int32_t Cin) { return (size_t)36 * Cout * Cin; }
+
+/* dx[nimg][H][W][Cin] = input gradient of the 3x3 convolution with kernel w[Cout][Cin][3][3] for the output gradient dy[nimg][H][W][Cout];
+ * U43 = vd_wino43_pack(w).  Every element of dx[..., :Cin] is written (no accumulation). */
+extern "C" int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const float* U43, float* dx, int64_t lddx, int32_t nimg, int32_t H,
+                                       int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+    VD_REQUIRE(dy && U43 && dx, "vd_conv3x3_dgrad_wino43: null operand");
+    VD_REQUIRE(vd_conv3x3_dgrad_wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx),
+               "vd_conv3x3_dgrad_wino43: unsupported geometry nimg=%d H=%d W=%d Cin=%d Cout=%d", nimg, H, W, Cin, Cout);
+    VD_REQUIRE(vd_aligned16(dy) && vd_aligned16(U43) && vd_aligned16(dx), "vd_conv3x3_dgrad_wino43: operands must be 16-byte aligned");
+    Args43 a = {};
+    a.x = dy; a.ldx = lddy; a.U = U43; a.y = dx; a.ldy = lddx;
+    a.nimg = nimg; a.H = H; a.W = W; a.K = Cout; a.N = Cin;
+    a.items_per_img = W == 32 ? 1 : H / 16;
+    a.ncb = Cin / TN;
+    const long long items = (long long)nimg * a.items_per_img * a.ncb;
+    VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_dgrad_wino43: too many work items");
+    a.nitems = (int)items;
+    const int ncu = vd_cu_count();
+    const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (W == 32) hipLaunchKernelGGL((wino43_dgrad_kernel<8>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((wino43_dgrad_kernel<16>), grid, blk, 0, st, a);
+    VD_LAUNCH_CHECK("wino43_dgrad_kernel");
+    g_last43 = W == 32 ? 8 : 16;
+    return 0;
+}
+
+/* tiles per row (8 / 16) of the calling thread's last vd_conv3x3_dgrad_wino43 launch = the instantiation wino43_dgrad_kernel<TWT> */
+extern "C" int vd_wino43_last_kernel(void) { return g_last43; }
+
+extern "C" int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, void* stream) {
+    VD_REQUIRE(w_oihw && U43 && Cout % KT == 0 && Cin % TN == 0, "vd_wino43_pack: needs Cout %% 8 == 0 and Cin %% 32 == 0");
+    hipLaunchKernelGGL(wino43_pack_kernel, dim3((unsigned)((Cin / TN) * (Cout / KT))), dim3(256), 0, (hipStream_t)stream, w_oihw, U43, Cout, Cin);
+    VD_LAUNCH_CHECK("wino43_pack_kernel");
+    return 0;
+}
+
+/* all tensors in one launch: items_dev = [n][8] int64 {w, U43, 0, Cout, Cin, 0, 0, first block}; a tensor takes (Cin/32)*(Cout/8) blocks */
+extern "C" int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream) {
+    VD_REQUIRE(items_dev && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "vd_wino43_pack_batched: bad table");
+    hipLaunchKernelGGL(wino43_pack_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(items_dev), n);
+    VD_LAUNCH_CHECK("wino43_pack_batched_kernel");
+    return 0;
+}

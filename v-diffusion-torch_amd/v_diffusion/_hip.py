@@ -48,6 +48,12 @@ _SIGNATURES = {
     "vd_wino_last_kernel": (C.c_int, []),
     "vd_wino_wgrad_last_kernel": (C.c_int, []),
     "vd_wino_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
+    "vd_conv3x3_dgrad_wino43_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "vd_wino43_u_floats": (_sz, [_i32, _i32]),
+    "vd_conv3x3_dgrad_wino43": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vd_wino43_last_kernel": (C.c_int, []),
+    "vd_wino43_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "vd_wino43_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
@@ -273,6 +279,31 @@ def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres
                 t.name = f"wino_conv_wide_kernel<{k // 2000}, {(k // 2) % 1000}, {'true' if k & 1 else 'false'}>"
             else:
                 t.name = t.name.format(tw=k // 2000, ns=(k // 2) % 1000, st="true" if k & 1 else "false")
+
+
+WINO43 = os.environ.get("VD_WINO43", "1") != "0"  # A/B switch: 0 keeps the input gradients on F(2x2,3x3)
+
+
+def wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx):
+    """input gradient of a Cin -> Cout convolution on (nimg, H, W) images through F(4x4,3x3)?"""
+    return WINO and WINO43 and bool(lib().vd_conv3x3_dgrad_wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx))
+
+
+def wino43_pack(w, Cout, Cin, U43):
+    _check(lib().vd_wino43_pack(ptr(w), Cout, Cin, ptr(U43), stream()), "vd_wino43_pack")
+
+
+def wino43_pack_batched(table, n, total_blocks):
+    assert table.is_cuda and table.dtype == torch.int64 and table.is_contiguous()
+    _check(lib().vd_wino43_pack_batched(table.data_ptr(), n, total_blocks, stream()), "vd_wino43_pack_batched")
+
+
+def conv3x3_dgrad_wino43(dy, lddy, U43, dx, lddx, nimg, H, W, Cin, Cout):
+    """dx = input gradient of the Cin -> Cout 3x3 convolution (Winograd F(4x4,3x3), see vd_conv3x3_dgrad_wino43); `flops` recorded =
+    the direct convolution's (algorithmic) count, of which the matrix cores execute 1/4"""
+    with _TimedName(f"wino43_dgrad_kernel<{W // 4}>", 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3_dgrad_wino43(ptr(dy), lddy, ptr(U43), ptr(dx), lddx, nimg, H, W, Cin, Cout, stream()),
+               "vd_conv3x3_dgrad_wino43")
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):
