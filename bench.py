@@ -143,8 +143,10 @@ def traffic_table():
 
 def executed_share(kernel_name):
     """MFMA FLOPs a kernel executes per ALGORITHMIC FLOP recorded for it (v_diffusion/_hip.py records 2*M*N*K of the op each
-    launch implements): Winograd F(2x2,3x3) kernels 4/9; the fused attention backward recomputes the logits in both of its
+    launch implements): Winograd F(2x2,3x3) kernels 4/9, the F(4x4,3x3) input gradient 1/4; the fused attention backward recomputes the logits in both of its
     kernels and dP in the second (7 products for the 4 the op defines: 7/4); everything else 1"""
+    if kernel_name.startswith("wino43_"):
+        return 1.0 / 4.0                      # F(4x4,3x3): 36 multiplies per 4x4 output tile where the convolution defines 144
     if kernel_name.startswith("wino_"):
         return 4.0 / 9.0
     if kernel_name.startswith("attn_bwd_"):

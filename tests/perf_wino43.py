@@ -55,3 +55,21 @@ for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256)
     fl = 2.0 * nimg * Hh * Ww * Cout * 9 * Cin
     print(f"{nimg}x{Hh}x{Ww} {Cout}->{Cin}: F(2,3) {t2:.3f} ms ({fl / t2 / 1e9:.0f} alg TF) err {e2:.2e} rel-L2 {r2:.2e} | "
           f"F(4,3) {t4:.3f} ms ({fl / t4 / 1e9:.0f} alg TF, {fl / 4 / t4 / 1e9:.0f} exe) err {e4:.2e} rel-L2 {r4:.2e} | scale {sc:.1f} | x{t2 / t4:.2f}")
+
+# ---- localisation aid when a kernel change breaks the result: one image, one K tile, delta kernels
+if os.environ.get("VD_W43_DEBUG"):
+    nimg, Hh, Ww, Cin, Cout = 1, 32, 32, 32, 8
+    dy = torch.randn((nimg, Hh, Ww, Cout), device=DEV)
+    for tap in ((1, 1), (0, 0), (2, 1)):
+        w = torch.zeros((Cout, Cin, 3, 3), device=DEV)
+        w[3, 5, tap[0], tap[1]] = 1.0
+        u43 = torch.empty(H.lib().vd_wino43_u_floats(Cout, Cin), device=DEV)
+        H.wino43_pack(w, Cout, Cin, u43)
+        dx4 = torch.full((nimg, Hh, Ww, Cin), 7.0, device=DEV)
+        H.conv3x3_dgrad_wino43(dy, Cout, u43, dx4, Cin, nimg, Hh, Ww, Cin, Cout)
+        ref = conv_fp64(dy, w.flip(2, 3).transpose(0, 1).contiguous())
+        err = (dx4.double() - ref).abs()
+        print("tap", tap, "max err", err.max().item(), "per-channel max err (nonzero):",
+              {c: round(err[..., c].max().item(), 3) for c in range(Cin) if err[..., c].max().item() > 1e-4})
+        e5 = err[0, :, :, 5]
+        print("  channel 5 error by (y % 4, x % 4):", [[round(e5[u::4, v::4].max().item(), 3) for v in range(4)] for u in range(4)])

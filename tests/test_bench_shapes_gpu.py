@@ -316,6 +316,38 @@ def test_wino_wgrad_at_bench_launches(H, case):
     print(f"wino wgrad {case[:5]} TWS={tws} slabs={slabs}: rel-L2 {rel:.2e}, max err {err:.2e} of {ref.abs().max().item():.2f}")
 
 
+@pytest.mark.parametrize("case", [c for c in WINO_BENCH if c[2] in (32, 64)], ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}to{c[4]}")
+def test_wino43_dgrad_at_bench_launches(H, case):
+    """vd_conv3x3_dgrad_wino43 (Winograd F(4x4,3x3): what the train step runs for the input gradients of the 32x32 / 64x64 layers)
+    at the bench launches, B = 128: 1024 work items = 4 persistent rounds per CU at 256 -> 256 @32x32, 3072 = 12 rounds at CelebA's
+    192 -> 192 @64x64.  Against fp64 on the device; the stated bound on gradients is relative L2 <= 1e-4, the kernel is held to 1.5e-5
+    (measured 3-4e-6) and 6e-5 of the largest element."""
+    nimg, Hh, Ww, Cin, Cout, _ = case
+    assert H.wino43_supported(nimg, Hh, Ww, Cin, Cout, Cout, Cin)
+    dy = _rand((nimg, Hh, Ww, Cout), 5)
+    w = _rand((Cout, Cin, 3, 3), 2, (9 * Cin) ** -0.5)
+    u43 = torch.empty(H.lib().vd_wino43_u_floats(Cout, Cin), device=DEV)
+    H.wino43_pack(w, Cout, Cin, u43)
+    dx = torch.full((nimg, Hh, Ww, Cin), 7.0, device=DEV)
+    H.conv3x3_dgrad_wino43(dy, Cout, u43, dx, Cin, nimg, Hh, Ww, Cin, Cout)
+    assert H.lib().vd_wino43_last_kernel() == Ww // 4
+    dx2 = torch.empty_like(dx)
+    H.conv3x3_dgrad_wino43(dy, Cout, u43, dx2, Cin, nimg, Hh, Ww, Cin, Cout)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2), "not bitwise reproducible"
+    ref = _conv_fp64_gpu(dy, w.flip(2, 3).transpose(0, 1).contiguous(), torch.zeros(Cin, device=DEV))
+    rel = ((dx.double() - ref).norm() / ref.norm()).item()
+    err = (dx.double() - ref).abs().max().item()
+    sc = ref.abs().max().item()
+    assert rel <= 1.5e-5 and err <= 6e-5 * sc, f"wino43 dgrad rel-L2 {rel:.3e}, max err {err:.3e} of {sc:.2f}"
+    # the device-side checker against fp64 autograd of F.conv2d on the host: first and last image
+    for i in (0, nimg - 1):
+        xz = torch.zeros(1, Cin, Hh, Ww, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xz, w.double().cpu(), padding=1).backward(dy[i:i + 1].permute(0, 3, 1, 2).double().cpu())
+        assert (xz.grad.permute(0, 2, 3, 1) - ref[i:i + 1].cpu()).abs().max().item() <= 1e-11 * max(sc, 1.0)
+    print(f"wino43 dgrad {case[:5]}: rel-L2 {rel:.2e}, max err {err:.2e} of {sc:.2f}")
+
+
 def test_cifar_train_step_b64_vs_oracle():
     """One full CIFAR-cond train-step forward/backward at B = 64 (every 32x32 conv launch has 512+ row tiles x 2 column tiles
     = the KT = 16 forms; the 32x32 weight gradients see 65536 pixels = the wide split-K form) against the CPU oracle on the
@@ -361,21 +393,28 @@ def test_cifar_train_step_b64_vs_oracle():
     def spy_wino(*a, **k):
         wino_calls[0] += 1
         return real_wino(*a, **k)
-    real_conv, real_wgrad, real_wino = _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino
-    _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino = spy_conv, spy_wgrad, spy_wino
+    w43_calls = [0]
+
+    def spy_w43(*a, **k):
+        w43_calls[0] += 1
+        return real_w43(*a, **k)
+    real_conv, real_wgrad, real_wino, real_w43 = _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43
+    _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43 = spy_conv, spy_wgrad, spy_wino, spy_w43
     try:
         loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
         loss.mean().backward()
         torch.cuda.synchronize()
     finally:
-        _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino = real_conv, real_wgrad, real_wino
+        _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43 = real_conv, real_wgrad, real_wino, real_w43
     code = lambda tr, kt: ((tr * 100 + kt) * 1000 + 128) * 1000 + 128
     if _hip.WINO:           # every residual-block convolution of this network is served by the Winograd kernels
-        assert wino_calls[0] == 108 and not any(k == "conv" for k, _ in seen), (wino_calls, sorted(seen))
+        # 54 forward launches + 54 input gradients, of which the 16 at 32x32 take the F(4x4,3x3) kernel (VD_WINO43=0: none)
+        n43 = 16 if _hip.WINO43 else 0
+        assert (wino_calls[0], w43_calls[0]) == (108 - n43, n43) and not any(k == "conv" for k, _ in seen), (wino_calls, w43_calls, sorted(seen))
         assert {k for k in seen if k[0] == "wgrad_wino"} == {("wgrad_wino", 16), ("wgrad_wino", 8), ("wgrad_wino", 4)}, sorted(seen)
         assert not any(k == "wgrad" for k, _ in seen), sorted(seen)
     else:                   # VD_WINO=0 (test_cifar_train_step_b64_direct_convolutions): the direct implicit-GEMM forms
-        assert ("conv", code(0, 16)) in seen and ("conv", code(1, 16)) in seen and wino_calls[0] == 0, sorted(seen)
+        assert ("conv", code(0, 16)) in seen and ("conv", code(1, 16)) in seen and wino_calls[0] == 0 and w43_calls[0] == 0, sorted(seen)
         assert ("wgrad", code(1, 16)) in seen and not any(k == "wgrad_wino" for k, _ in seen), sorted(seen)
     # ---- CPU oracle, same weights / inputs
     torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
@@ -438,7 +477,7 @@ def test_celeba_train_step_b8_vs_oracle():
     gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), 50, "v", "fixed_medium", "snr_trunc",
                                        "mse", intp_frac=0.3, w_guide=1.0, p_uncond=0.0)
     wino_calls, fused = [0], [0]
-    real_wino, real_attn = _hip.conv3x3_wino, _hip.attn_bwd
+    real_wino, real_attn, real_w43 = _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43
 
     def spy_wino(*a, **k):
         wino_calls[0] += 1
@@ -447,15 +486,15 @@ def test_celeba_train_step_b8_vs_oracle():
     def spy_attn(*a, **k):
         fused[0] += 1
         return real_attn(*a, **k)
-    _hip.conv3x3_wino, _hip.attn_bwd = spy_wino, spy_attn
+    _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43 = spy_wino, spy_attn, spy_wino
     try:
         loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
         loss.mean().backward()
         torch.cuda.synchronize()
     finally:
-        _hip.conv3x3_wino, _hip.attn_bwd = real_wino, real_attn
+        _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43 = real_wino, real_attn, real_w43
     if _hip.WINO:
-        assert wino_calls[0] == 2 * 2 * 36, wino_calls            # 36 residual blocks x 2 convolutions x (forward + input gradient)
+        assert wino_calls[0] == 2 * 2 * 36, wino_calls            # 36 residual blocks x 2 convolutions x (forward + input gradient), both Winograd orders
     if _hip.FUSED_ATTN:
         assert fused[0] == 27, fused                              # every attention block of the merged config (head dim 64)
     torch.set_num_threads(_oracle_threads())

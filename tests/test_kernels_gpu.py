@@ -882,3 +882,55 @@ def test_conv3x3_wgrad_wino(H, case):
     H.conv3x3_wgrad_wino(xd, Cin + ex, dyd, Cout + ey, nimg, Hh, Ww, Cin, Cout, b, Cin_w, Cout_w)
     assert torch.equal(a, b), "not bitwise reproducible"
     close(a, w64.grad, w32.grad, slack=8.0, floor=4e-6, name="wino wgrad (no accumulate, no bias)")
+
+
+# ------------------------------------------------------------------------------------------------ Winograd F(4x4,3x3) input gradient
+WINO43_CASES = [  # nimg, H, W, Cin, Cout, lddy_extra, lddx_extra
+    (2, 32, 32, 32, 8, 0, 0),          # one K tile, one channel block
+    (3, 32, 32, 96, 24, 8, 32),        # 3 images x 3 channel blocks = 9 items (plain ids), ld > C on both sides
+    (8, 32, 32, 128, 64, 0, 0),        # 8 tile groups x 4 channel blocks: the XCD-aware 4 x 8 item order
+    (1, 16, 64, 32, 16, 0, 0),         # 64-wide image, one 16-row part
+    (2, 64, 64, 64, 40, 0, 0),         # 64x64: 4 parts per image (interior parts have halo rows on both sides)
+    (40, 32, 32, 256, 256, 0, 0),      # 40 x 8 = 320 items: one full persistent round (permuted ids) + a ragged one
+]
+
+
+@pytest.mark.parametrize("case", WINO43_CASES)
+def test_conv3x3_dgrad_wino43(H, case):
+    """vd_conv3x3_dgrad_wino43 == autograd of F.conv2d with respect to its input (fp64 truth).  F(4x4,3x3) in fp32 carries about
+    7x the rounding error of a direct fp32 sum (measured: relative L2 3-4e-6, max 1.5e-5 of the largest element at K = 256), which
+    is why it serves gradients only (stated bound on gradients: relative L2 <= 1e-4): bounds here 1.5e-5 relative L2 and 6e-5 of
+    the largest element.  Bitwise reproducible; padding channels of dx untouched."""
+    nimg, Hh, Ww, Cin, Cout, ey, ex = case
+    assert H.lib().vd_conv3x3_dgrad_wino43_supported(nimg, Hh, Ww, Cin, Cout, Cout + ey, Cin + ex) == 1
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    dy = rnd(nimg, Cout, Hh, Ww, seed=5)
+    x64 = torch.zeros(nimg, Cin, Hh, Ww, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x64, w.double(), padding=1).backward(dy.double())
+    u43 = torch.empty(H.lib().vd_wino43_u_floats(Cout, Cin), device=DEV)
+    H.wino43_pack(w.to(DEV), Cout, Cin, u43)
+    dx = torch.full((nimg, Hh, Ww, Cin + ex), 5.0, device=DEV)
+    H.conv3x3_dgrad_wino43(nhwc(dy, Cout + ey), Cout + ey, u43, dx, Cin + ex, nimg, Hh, Ww, Cin, Cout)
+    assert H.lib().vd_wino43_last_kernel() == Ww // 4
+    dx2 = torch.full_like(dx, 5.0)
+    H.conv3x3_dgrad_wino43(nhwc(dy, Cout + ey), Cout + ey, u43, dx2, Cin + ex, nimg, Hh, Ww, Cin, Cout)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2), "not bitwise reproducible"
+    if ex:
+        assert (dx[..., Cin:] == 5.0).all(), "padding channels of dx were written"
+    got, ref = from_nhwc(dx, Cin).double().cpu(), x64.grad
+    rel = ((got - ref).norm() / ref.norm()).item()
+    err = (got - ref).abs().max().item()
+    assert rel <= 1.5e-5 and err <= 6e-5 * ref.abs().max().item(), f"wino43 dgrad rel-L2 {rel:.3e}, max err {err:.3e} of {ref.abs().max().item():.2f}"
+
+
+def test_conv3x3_dgrad_wino43_rejects_unsupported(H):
+    f = H.lib().vd_conv3x3_dgrad_wino43_supported
+    assert f(2, 16, 16, 32, 32, 32, 32) == 0             # 16x16 images (served by the F(2x2,3x3) kernels)
+    assert f(2, 32, 32, 48, 32, 32, 48) == 0             # Cin % 32
+    assert f(2, 32, 32, 32, 12, 12, 32) == 0             # Cout % 8
+    assert f(2, 24, 64, 32, 32, 32, 32) == 0             # 64-wide, H % 16
+    assert f(2, 32, 32, 32, 32, 32, 32) == 1
+    z = torch.zeros(2, 16, 16, 32, device=DEV)
+    with pytest.raises(H.HipError, match="unsupported geometry"):
+        H.conv3x3_dgrad_wino43(z, 32, torch.zeros(36 * 32 * 32, device=DEV), torch.empty_like(z), 32, 2, 16, 16, 32, 32)

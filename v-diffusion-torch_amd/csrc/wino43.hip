@@ -108,10 +108,9 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
     // ---- DMA plan of this wave.  Patch pieces: granule wave & 1, slot groups (wave >> 1) + 4 j; U pieces wave + 8 j (linear copy).
     constexpr int APL = (NPG + 3) / 4;
     unsigned pxo[APL];
-    auto offsets = [&](int item) {
-        const int img = item / (p.ncb * p.items_per_img) * 1;   // (item = (img * items_per_img + part) * ncb + cb)
-        const int rem = item - img * (p.ncb * p.items_per_img);
-        const int part = rem / p.ncb;
+    auto offsets = [&](int grp) {                                   // tile group = (image, part of the image)
+        const int img = grp / p.items_per_img;
+        const int part = grp - img * p.items_per_img;
         const int y_first = 4 * NTR * part - 1;
 #pragma unroll
         for (int j = 0; j < APL; ++j) {
@@ -154,11 +153,42 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
     auto poff = [](int pr, int q) { return (pr * RP + (q & 3) * RUN + (q >> 2)) * 4; };
     const int uoff = A_STAGE + lane * 4;
 
+    // item of round n: linear id n * G + w, re-ordered inside FULL rounds so that the workgroups of one XCD (w % 8) take 32
+    // neighbouring ids, and 32 neighbouring ids are 4 channel blocks x 8 tile groups: the 4 blocks of a tile group share its patch
+    // stream in that XCD's L2, the 8 tile groups of a block share its U stream (as in wino.hip)
+    const int ngrp = p.nimg * p.items_per_img;                      // tile groups (64 tiles each)
+    auto item_of = [&](int n, int& cb, int& grp) -> bool {
+        int t = n * G + (int)blockIdx.x;
+        if ((G & 7) == 0 && (n + 1) * G <= p.nitems) t = n * G + ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+        if (t >= p.nitems) return false;
+        if ((p.ncb & 3) == 0 && (ngrp & 7) == 0) {
+            const int c = t >> 5, i = t & 31, ncg = p.ncb >> 2;
+            cb = (c % ncg) * 4 + (i & 3); grp = (c / ncg) * 8 + (i >> 2);
+            return true;
+        }
+        cb = t % p.ncb; grp = t / p.ncb;
+        return true;
+    };
+
     auto run = [&](auto Hc) {
         constexpr int HALF = decltype(Hc)::value;
-        for (int item = blockIdx.x; item < p.nitems; item += G) {
-            const int cb = item % p.ncb;
-            offsets(item);
+        // row pass of one K tile: R[a'][q] = sum_p B^T[3 HALF + a'][p] d[p][q]  (five of the six patch rows), columns q0 .. q1-1
+        auto rowpass = [&](const float* sa, f32x2 (&Rn)[3][6], int q0, int q1) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (q < q0 || q >= q1) continue;
+                f32x2 d[6];
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    if ((HALF == 0 && pr == 5) || (HALF == 1 && pr == 0)) d[pr] = f32x2{0.f, 0.f};
+                    else d[pr] = *reinterpret_cast<const f32x2*>(sa + poff(pr, q));
+                }
+                bt_half<HALF>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
+            }
+        };
+        int cb = 0, grp = 0;
+        for (int n = 0; item_of(n, cb, grp); ++n) {
+            offsets(grp);
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) issue_piece(i, 0, 0, cb);
             f32x4 acc[18][2];
@@ -166,24 +196,24 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             for (int x = 0; x < 18; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (nkt > 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) issue_piece(i, 1, 1, cb);
+            }
+            f32x2 R[3][6];
+            rowpass(smem + pbase, R, 0, 6);
+            // K loop.  Tile kt lives in stage kt & 1.  ONE barrier per tile, in front of step SB = 15 of its 18 MFMA steps, with the
+            // U fragments of steps 15..17 already in registers: behind it stage kt is dead (the patch of tile kt was consumed
+            // during tile kt-1) and stage kt+1 has landed, so the remaining three steps run beside the row pass of tile kt+1 --
+            // the transform no longer opens every tile with both waves of a SIMD waiting on LDS -- and the DMA of tile kt+2
+            // starts into the stage just vacated (pieces 0..2 in steps 15..17, the rest in the first steps of tile kt+1).
             for (int kt = 0; kt < nkt; ++kt) {
                 const int st = kt & 1;
-                const float* sa = smem + st * STAGE + pbase;
                 const float* su = smem + st * STAGE + uoff;
-                const bool dma = kt + 1 < nkt;
-                // row pass: R[a'][q] = sum_p B^T[3 HALF + a'][p] d[p][q]  (five of the six patch rows)
-                f32x2 R[3][6];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    f32x2 d[6];
-#pragma unroll
-                    for (int pr = 0; pr < 6; ++pr) {
-                        if ((HALF == 0 && pr == 5) || (HALF == 1 && pr == 0)) d[pr] = f32x2{0.f, 0.f};
-                        else d[pr] = *reinterpret_cast<const f32x2*>(sa + poff(pr, q));
-                    }
-                    bt_half<HALF>(d, R[0][q], R[1][q], R[2][q]);
-                }
-                f32x4 uf[2];
+                const float* san = smem + (st ^ 1) * STAGE + pbase;
+                const bool n1 = kt + 1 < nkt, n2 = kt + 2 < nkt;
+                f32x2 Rn[3][6];
+                f32x4 uf[2], ufl[3];
                 uf[0] = *reinterpret_cast<const f32x4*>(su + (18 * HALF) * 256);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -192,18 +222,32 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
 #pragma unroll
                     for (int b = 0; b < 6; ++b) {
                         const int xl = 6 * a + b;
-                        if (xl < 17) uf[(xl + 1) & 1] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + 1) * 256);
-                        if (dma && xl < NPIECE) issue_piece(xl, kt + 1, st ^ 1, cb);
-                        const f32x4 u = uf[xl & 1];
+                        if (xl == 15) {
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) ufl[e] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + 15 + e) * 256);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                        }
+                        if (xl < 14) uf[(xl + 1) & 1] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + 1) * 256);
+                        if (xl + 3 < NPIECE) { if (n1) issue_piece(xl + 3, kt + 1, st ^ 1, cb); }
+                        if (xl >= 15) {
+                            if (n2) issue_piece(xl - 15, kt + 2, st, cb);
+                            rowpass(san, Rn, 2 * (xl - 15), 2 * (xl - 15) + 2);     // (last tile: a stale stage, result unused)
+                        }
+                        const f32x4 u = xl < 15 ? uf[xl & 1] : ufl[xl < 15 ? 0 : xl - 15];
                         acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], V[b][0], acc[xl][0], 0, 0, 0);
                         acc[xl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], V[b][0], acc[xl][1], 0, 0, 0);
                         acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], V[b][1], acc[xl][0], 0, 0, 0);
                         acc[xl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3], V[b][1], acc[xl][1], 0, 0, 0);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                // (unconditional: a select here would keep both R and Rn alive across the whole tile)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) R[a][q] = Rn[a][q];
             }
+            __syncthreads();                                        // every wave is through its last three steps: the stages are dead
 
             // ---------------- epilogue: dx = A^T M A      A^T = [1 1 1 1 1 0 ; 0 1 -1 2 -2 0 ; 0 1 1 4 4 0 ; 0 1 -1 8 -8 1]
             // this wave holds rows a = 3 HALF + a' of M for both channel blocks: column pass in registers, then its partial row
@@ -252,8 +296,8 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             }
             {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const int img = item / (p.ncb * p.items_per_img);
-                const int part = (item - img * (p.ncb * p.items_per_img)) / p.ncb;
+                const int img = grp / p.items_per_img;
+                const int part = grp - img * p.items_per_img;
                 const int n0 = cb * TN + 16 * HALF + 4 * lq;
                 const int y0 = 4 * (NTR * part + tyl), x0 = 4 * tx;
                 const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);

@@ -169,16 +169,34 @@ class UNetEngine:
 
     PACK_STATES_MAX = 4       # weight sets (raw / EMA) x (training / inference) whose packed images are kept at a time
 
-    def _pack_all(self, need_d):
+    def _conv_geoms(self, B, H0, W0):
+        """[(weight, rows, H, W, Cin, Cout)] of every residual-block convolution for a (B, C, H0, W0) input: the resolution its two
+        convolutions run at (a down-sampling block pools in front of conv1, an up-sampling block up-samples in front of it)"""
+        out = []
+        for b in self.plan:
+            if b.res is None:
+                continue
+            lh, lw = self._res_of(b.level, H0, W0)
+            if b.rs == H.RS_DOWN:
+                lh, lw = lh // 2, lw // 2
+            elif b.rs == H.RS_UP:
+                lh, lw = lh * 2, lw * 2
+            out.append((b.res.conv1.weight, B, lh, lw, b.cin, b.cout))
+            out.append((b.res.conv2.weight, B, lh, lw, b.cout, b.cout))
+        return out
+
+    def _pack_all(self, need_d, geom=None):
         """Re-pack the 3x3 kernels of every residual block in ONE launch (vd_wino_pack_batched / vd_pack_conv3x3_batched) into
         persistent buffers; returns {id(weight): (forward pack, dgrad pack or None)}.
         Pack state (buffers + device table) is kept PER WEIGHT SET -- the key is the parameters' storage pointers, so raw
         weights and an EMA view swap (trainer.ema_weights) each keep their own stable buffers and table instead of freeing and
         re-allocating them on every alternation -- in a small LRU.  ``self._last_pack_state`` is the state the last forward
         used: a captured HIP graph keeps a reference to it, so the table / U images its pack and convolution nodes point to
-        stay allocated for as long as the graph is cached (diffusion._sample_loop_graph)."""
+        stay allocated for as long as the graph is cached (diffusion._sample_loop_graph).
+        ``geom`` = (B, H0, W0) of the training input: the input gradients of the layers vd_conv3x3_dgrad_wino43 serves at that
+        geometry take the F(4x4,3x3) image U43 instead of the rotated F(2x2,3x3) one."""
         ws = [c.weight for b in self.plan if b.res is not None for c in (b.res.conv1, b.res.conv2)]
-        key = (bool(need_d), H.WINO) + tuple(w.data_ptr() for w in ws)
+        key = (bool(need_d), H.WINO, geom if need_d else None) + tuple(w.data_ptr() for w in ws)
         if self._pack_state is None:
             self._pack_state = {}
         st = self._pack_state.pop(key, None)             # (re-inserted below as the most recent entry)
@@ -187,21 +205,40 @@ class UNetEngine:
             sizes = [w.numel() for w in ws]
             st = dict(n=len(ws))
             if H.WINO:
-                # Winograd-domain kernels U = G w G^T (csrc/wino.hip): [16][Cout][Cin] forward, [16][Cin][Cout] input gradient
+                # Winograd-domain kernels U = G w G^T (csrc/wino.hip): [16][Cout][Cin] forward, [16][Cin][Cout] input gradient;
+                # csrc/wino43.hip: 36 x Cin x Cout in lane order for the input gradients it serves
+                use43 = {}
+                if need_d and geom is not None:
+                    for (w, nb, lh, lw, ci, co) in self._conv_geoms(*geom):
+                        use43[id(w)] = H.wino43_supported(nb, lh, lw, ci, co, co, ci)
                 uf_all = torch.empty(16 * sum(sizes) // 9, dtype=torch.float32, device=dev)
-                ud_all = torch.empty_like(uf_all) if need_d else None
-                wrows, wviews, woff, wblk = [], {}, 0, 0
+                nd = sum(n for w, n in zip(ws, sizes) if not use43.get(id(w))) if need_d else 0
+                n43 = sum(n for w, n in zip(ws, sizes) if use43.get(id(w)))
+                ud_all = torch.empty(16 * nd // 9, dtype=torch.float32, device=dev) if nd else None
+                u43_all = torch.empty(36 * n43 // 9, dtype=torch.float32, device=dev) if n43 else None
+                wrows, wviews, woff, doff, wblk = [], {}, 0, 0, 0
+                rows43, off43, blk43 = [], 0, 0
                 for w, n in zip(ws, sizes):
                     co, ci = w.shape[0], w.shape[1]
                     m = 16 * co * ci
                     uf = uf_all[woff: woff + m].view(16, co, ci)
-                    ud = ud_all[woff: woff + m].view(16, ci, co) if need_d else None
+                    ud = u43 = None
+                    if need_d and use43.get(id(w)):
+                        u43 = u43_all[off43: off43 + 36 * co * ci]
+                        rows43.append([w.data_ptr(), u43.data_ptr(), 0, co, ci, 0, 0, blk43])
+                        off43 += 36 * co * ci
+                        blk43 += (ci // 32) * (co // 8)
+                    elif need_d:
+                        ud = ud_all[doff: doff + m].view(16, ci, co)
+                        doff += m
                     tiled = int(co % 16 == 0 and ci % 16 == 0)
-                    wrows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr() if need_d else 0, co, ci, tiled, 0, wblk])
-                    wviews[id(w)] = (uf, ud)
+                    wrows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr() if ud is not None else 0, co, ci, tiled, 0, wblk])
+                    wviews[id(w)] = (uf, ud, u43)
                     woff += m
                     wblk += (co // 16) * (ci // 16) if tiled else (co * ci + 255) // 256
-                st.update(uf=uf_all, ud=ud_all, wtable=torch.tensor(wrows, dtype=torch.int64).to(dev), wblocks=wblk, wviews=wviews)
+                st.update(uf=uf_all, ud=ud_all, u43=u43_all, wtable=torch.tensor(wrows, dtype=torch.int64).to(dev), wblocks=wblk,
+                          wviews=wviews, table43=torch.tensor(rows43, dtype=torch.int64).to(dev) if rows43 else None,
+                          n43=len(rows43), blocks43=blk43)
             else:
                 wf_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
                 wd_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev) if need_d else None
@@ -223,6 +260,8 @@ class UNetEngine:
             # every convolution the Winograd kernels serve needs only U; the direct packs are made per tensor, on demand, by
             # _pack_f / _pack_d for the geometries that fall back (none in the shipped configs)
             H.wino_pack_batched(st["wtable"], st["n"], st["wblocks"])
+            if st["n43"]:
+                H.wino43_pack_batched(st["table43"], st["n43"], st["blocks43"])
             self._wino = st["wviews"]
             return {}
         H.pack_conv3x3_batched(st["table"], st["n"], st["blocks"])
@@ -233,6 +272,11 @@ class UNetEngine:
         """3x3 convolution with kernel ``w`` (forward) or its input gradient (``dgrad``: x = dy, Cin/Cout are the GEMM's):
         Winograd F(2x2,3x3) wherever the geometry is served, the direct implicit GEMM otherwise."""
         wino = getattr(self, "_wino", None)
+        if wino is not None and dgrad and id(w) in wino and wino[id(w)][2] is not None:
+            # F(4x4,3x3) input gradient (csrc/wino43.hip): x = dy [.., Cin = conv Cout], y = dx [.., Cout = conv Cin]
+            assert res is None and bias is None and stats_part is None
+            H.conv3x3_dgrad_wino43(x, ldx, wino[id(w)][2], y, ldy, B, Hh, Ww, Cout, Cin)
+            return
         if wino is not None and id(w) in wino and H.wino_supported(B, Hh, Ww, Cin, Cout, ldx, ldy, ldres if res is not None else 0):
             U = wino[id(w)][1 if dgrad else 0]
             if U is not None:
@@ -567,7 +611,7 @@ class UNetEngine:
         if cache is not None and "all" in cache:
             self._packed = cache["all"]                  # a sampler holds the weights fixed: packed once per chain
         else:
-            self._packed = self._pack_all(need_d=save)
+            self._packed = self._pack_all(need_d=save, geom=(B, H0, W0))
             if cache is not None:
                 cache["all"] = self._packed
         ta = self._embed_fwd(t, y, tape)
