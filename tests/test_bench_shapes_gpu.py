@@ -486,7 +486,10 @@ def test_celeba_train_step_b8_vs_oracle():
     def spy_attn(*a, **k):
         fused[0] += 1
         return real_attn(*a, **k)
-    _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43 = spy_wino, spy_attn, spy_wino
+    def spy_w43(*a, **k):
+        wino_calls[0] += 1
+        return real_w43(*a, **k)
+    _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43 = spy_wino, spy_attn, spy_w43
     try:
         loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
         loss.mean().backward()

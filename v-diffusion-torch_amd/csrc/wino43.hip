@@ -55,31 +55,79 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
 }
 
-// 1-D input transform B^T of F(4,3), rows {0,1,2} (HALF = 0) or {3,4,5} (HALF = 1), on two channels at once.
+// 1-D input transform B^T of F(4,3), rows {0,1,2} (HALF = 0) or {3,4,5} (HALF = 1).
 //   B^T = [4 0 -5 0 1 0 ; 0 -4 -4 1 1 0 ; 0 4 -4 -1 1 0 ; 0 -2 -1 2 1 0 ; 0 2 -1 -2 1 0 ; 0 4 0 -5 0 1]
-template <int HALF>
-__device__ __forceinline__ void bt_half(const f32x2 (&d)[6], f32x2& o0, f32x2& o1, f32x2& o2) {
+// The transforms run on the two channels of a lane as packed fp32 instructions (v_pk_fma_f32 / v_pk_add_f32).  A/B on MI355X against
+// scalar instructions (-DVD_W43_PACKED=0 -fno-slp-vectorize): 0.460 vs 0.464 ms at 256 -> 256 @32x32 -- no difference, the packed
+// form is kept for its instruction count.
+#ifndef VD_W43_PACKED
+#define VD_W43_PACKED 1
+#endif
+// timing experiments (WRONG results; built only by tests/probe/w43_exp.sh into scratch libraries, never into the product or the
+// probe library): 1 = no DMA inside the K loop, 2 = also no transform arithmetic, 3 = also no patch reads, 4 = also no U-fragment
+// reads, 5 = full kernel without the tile barrier
+#ifndef VD_W43_EXP
+#define VD_W43_EXP 0
+#endif
+#ifndef VD_W43_SB
+#define VD_W43_SB 12          /* MFMA step (of 18 per K tile) the tile barrier sits in front of */
+#endif
+#ifndef VD_W43_DPS
+#define VD_W43_DPS 1          /* DMA pieces of tile kt+2 issued per step behind the barrier */
+#endif
+template <int HALF, typename T>
+__device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
     if (HALF == 0) {
-        const f32x2 t = d[4] - 4.f * d[2], u = d[3] - 4.f * d[1];
+        const T t = d[4] - 4.f * d[2], u = d[3] - 4.f * d[1];
         o0 = 4.f * d[0] + (d[4] - 5.f * d[2]);
         o1 = t + u;
         o2 = t - u;
     } else {
-        const f32x2 c = d[4] - d[2], e = d[3] - d[1];
+        const T c = d[4] - d[2], e = d[3] - d[1];
         o0 = c + 2.f * e;
         o1 = c - 2.f * e;
         o2 = 4.f * d[1] + (d[5] - 5.f * d[3]);
     }
 }
 // all six outputs (the column pass)
-__device__ __forceinline__ void bt_full(const f32x2 (&r)[6], f32x2 (&v)[6]) {
-    const f32x2 t = r[4] - 4.f * r[2], u = r[3] - 4.f * r[1], c = r[4] - r[2], e = r[3] - r[1];
+template <typename T>
+__device__ __forceinline__ void bt_full(const T (&r)[6], T (&v)[6]) {
+    const T t = r[4] - 4.f * r[2], u = r[3] - 4.f * r[1], c = r[4] - r[2], e = r[3] - r[1];
     v[0] = 4.f * r[0] + (r[4] - 5.f * r[2]);
     v[1] = t + u;
     v[2] = t - u;
     v[3] = c + 2.f * e;
     v[4] = c - 2.f * e;
     v[5] = 4.f * r[1] + (r[5] - 5.f * r[3]);
+}
+// the two channels of a lane: f32x2 in, transform per channel (scalar build) or on the pair (packed build)
+template <int HALF>
+__device__ __forceinline__ void bt_half2(const f32x2 (&d)[6], f32x2& o0, f32x2& o1, f32x2& o2) {
+#if VD_W43_PACKED
+    bt_half<HALF, f32x2>(d, o0, o1, o2);
+#else
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float dj[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float a, b, c;
+        bt_half<HALF, float>(dj, a, b, c);
+        o0[j] = a; o1[j] = b; o2[j] = c;
+    }
+#endif
+}
+__device__ __forceinline__ void bt_full2(const f32x2 (&r)[6], f32x2 (&v)[6]) {
+#if VD_W43_PACKED
+    bt_full<f32x2>(r, v);
+#else
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float rj[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
+        float vj[6];
+        bt_full<float>(rj, vj);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) v[b][j] = vj[b];
+    }
+#endif
 }
 
 // TWT = tiles per image row (8: 32-wide images, 16: 64-wide images)
@@ -145,6 +193,10 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
         }
     };
     constexpr int NPIECE = 5 + APL;
+    // the tile barrier sits in front of MFMA step SB of 18; the NAFTER steps behind it carry the row pass of the next tile and DPS DMA
+    // pieces each of the tile after that
+    constexpr int SB = VD_W43_SB, NAFTER = 18 - SB, DPS = VD_W43_DPS, PAFTER = NAFTER * DPS;
+    static_assert(PAFTER <= NPIECE && NPIECE - PAFTER <= SB, "DMA schedule does not fit the tile");
 
     // ---- LDS read addresses (floats): patch position (pr, q) of this lane's tile, channels {2 lq, 2 lq + 1}
     const int tl = 16 * tg + li;
@@ -181,9 +233,11 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr) {
                     if ((HALF == 0 && pr == 5) || (HALF == 1 && pr == 0)) d[pr] = f32x2{0.f, 0.f};
+                    else if (VD_W43_EXP >= 3 && VD_W43_EXP <= 4) d[pr] = f32x2{(float)pr, (float)q};
                     else d[pr] = *reinterpret_cast<const f32x2*>(sa + poff(pr, q));
                 }
-                bt_half<HALF>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
+                if (VD_W43_EXP >= 2 && VD_W43_EXP <= 4) { Rn[0][q] = d[1]; Rn[1][q] = d[2]; Rn[2][q] = d[3]; }
+                else bt_half2<HALF>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
             }
         };
         int cb = 0, grp = 0;
@@ -198,12 +252,12 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             __syncthreads();
             if (nkt > 1) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) issue_piece(i, 1, 1, cb);
+                for (int i = 0; i < PAFTER; ++i) issue_piece(i, 1, 1, cb);
             }
             f32x2 R[3][6];
             rowpass(smem + pbase, R, 0, 6);
-            // K loop.  Tile kt lives in stage kt & 1.  ONE barrier per tile, in front of step SB = 15 of its 18 MFMA steps, with the
-            // U fragments of steps 15..17 already in registers: behind it stage kt is dead (the patch of tile kt was consumed
+            // K loop.  Tile kt lives in stage kt & 1.  ONE barrier per tile, in front of step SB of its 18 MFMA steps, with the
+            // U fragments of steps SB..17 already in registers: behind it stage kt is dead (the patch of tile kt was consumed
             // during tile kt-1) and stage kt+1 has landed, so the remaining three steps run beside the row pass of tile kt+1 --
             // the transform no longer opens every tile with both waves of a SIMD waiting on LDS -- and the DMA of tile kt+2
             // starts into the stage just vacated (pieces 0..2 in steps 15..17, the rest in the first steps of tile kt+1).
@@ -213,28 +267,36 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
                 const float* san = smem + (st ^ 1) * STAGE + pbase;
                 const bool n1 = kt + 1 < nkt, n2 = kt + 2 < nkt;
                 f32x2 Rn[3][6];
-                f32x4 uf[2], ufl[3];
+                f32x4 uf[2], ufl[NAFTER];
                 uf[0] = *reinterpret_cast<const f32x4*>(su + (18 * HALF) * 256);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     f32x2 V[6];
-                    bt_full(R[a], V);
+                    if (VD_W43_EXP >= 2 && VD_W43_EXP <= 4) {
+#pragma unroll
+                        for (int b = 0; b < 6; ++b) V[b] = R[a][b];
+                    } else bt_full2(R[a], V);
 #pragma unroll
                     for (int b = 0; b < 6; ++b) {
                         const int xl = 6 * a + b;
-                        if (xl == 15) {
+                        if (xl == SB) {
 #pragma unroll
-                            for (int e = 0; e < 3; ++e) ufl[e] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + 15 + e) * 256);
+                            for (int e = 0; e < NAFTER; ++e) ufl[e] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + SB + e) * 256);
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __syncthreads();
+                            if (VD_W43_EXP != 5) __syncthreads();
                         }
-                        if (xl < 14) uf[(xl + 1) & 1] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + 1) * 256);
-                        if (xl + 3 < NPIECE) { if (n1) issue_piece(xl + 3, kt + 1, st ^ 1, cb); }
-                        if (xl >= 15) {
-                            if (n2) issue_piece(xl - 15, kt + 2, st, cb);
-                            rowpass(san, Rn, 2 * (xl - 15), 2 * (xl - 15) + 2);     // (last tile: a stale stage, result unused)
+                        if (xl < SB - 1 && VD_W43_EXP != 4) uf[(xl + 1) & 1] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + 1) * 256);
+                        // DMA of tile kt+1: pieces PAFTER .. NPIECE-1 in the first steps of this tile (pieces 0 .. PAFTER-1 went out behind
+                        // the barrier of tile kt-1); DMA of tile kt+2: pieces 0 .. PAFTER-1 behind this tile's barrier
+                        if (xl + PAFTER < NPIECE && !(VD_W43_EXP >= 1 && VD_W43_EXP <= 4)) { if (n1) issue_piece(xl + PAFTER, kt + 1, st ^ 1, cb); }
+                        if (xl >= SB) {
+                            if (n2 && !(VD_W43_EXP >= 1 && VD_W43_EXP <= 4)) {
+#pragma unroll
+                                for (int e = 0; e < DPS; ++e) issue_piece((xl - SB) * DPS + e, kt + 2, st, cb);
+                            }
+                            rowpass(san, Rn, (6 * (xl - SB)) / NAFTER, (6 * (xl - SB + 1)) / NAFTER);     // (last tile: a stale stage, result unused)
                         }
-                        const f32x4 u = xl < 15 ? uf[xl & 1] : ufl[xl < 15 ? 0 : xl - 15];
+                        const f32x4 u = xl < SB ? uf[xl & 1] : ufl[xl < SB ? 0 : xl - SB];
                         acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], V[b][0], acc[xl][0], 0, 0, 0);
                         acc[xl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], V[b][0], acc[xl][1], 0, 0, 0);
                         acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], V[b][1], acc[xl][0], 0, 0, 0);
