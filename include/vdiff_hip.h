@@ -222,6 +222,15 @@ int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, 
  * -1 for the two-pass form (chan_reduce_kernel<1> + gn_bwd_finalize_kernel + gn_bwd_apply_kernel), 0 without a norm (plain resample
  * backward: gn_bwd_apply_kernel).  Profiling aid, like vd_gemm_last_tile. */
 int vd_gn_bwd_last_kernel(void);
+/* vd_gn_apply_bwd with the sum over images of the per-image dgamma / dbeta terms left to the caller: they are written to
+ * pgb_keep[nimg][2][C] ({dgamma, dbeta} terms) and ONE vd_gn_param_sums_batched launch sums them for all norms of a backward pass
+ * (the per-norm launch is pure latency: 73 per CIFAR train step).  items_dev = [n][8] int64 {pgb, dgamma, dbeta, nimg, C, accumulate, 0,
+ * first 256-thread block}; a norm takes ceil(C / 16) blocks. */
+int vd_gn_apply_bwd_keep(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef, const float* gamma,
+                         const float* beta, const float* film, int32_t act, float p_drop, uint64_t seed, int32_t resample,
+                         const float* add, int64_t ldadd, float* dx, int64_t lddx, int32_t accumulate_dx, float* dfilm, float* pgb_keep,
+                         int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* ws, size_t ws_bytes, void* stream);
+int vd_gn_param_sums_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
 
 /* ------------------------------------------------------------------ small reductions / elementwise
  * out[n] (+)= sum_m x[m][n]   (bias gradients) */

@@ -73,8 +73,10 @@ if __name__ == "__main__":
     print("---- CelebA 64x64 model (hd 64), batch 128")
     for L in (64, 256, 1024, 4096):
         case(128, 1, L, 64)
-    print("---- CIFAR-10 model (hd 256): forward only (sampling, 256 rows)")
+    print("---- CIFAR-10 model (hd 256): sampling (256 rows, forward) and training (128 rows, forward + backward)")
     for L in (64, 256, 1024):
         case(256, 1, L, 256, bwd=False)
+    for L in (64, 256, 1024):
+        case(128, 1, L, 256)
     print("---- hd 128")
     case(64, 2, 1024, 128)

@@ -393,19 +393,29 @@ def test_cifar_train_step_b64_vs_oracle():
     def spy_wino(*a, **k):
         wino_calls[0] += 1
         return real_wino(*a, **k)
-    w43_calls = [0]
+    w43_calls, attn_bwd_calls = [0], [0]
 
     def spy_w43(*a, **k):
         w43_calls[0] += 1
         return real_w43(*a, **k)
-    real_conv, real_wgrad, real_wino, real_w43 = _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43
-    _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43 = spy_conv, spy_wgrad, spy_wino, spy_w43
+
+    def spy_attn_bwd(*a, **k):
+        attn_bwd_calls[0] += 1
+        return real_attn_bwd(*a, **k)
+    real_conv, real_wgrad, real_wino, real_w43, real_attn_bwd = (_hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino,
+                                                                 _hip.conv3x3_dgrad_wino43, _hip.attn_bwd)
+    _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43, _hip.attn_bwd = (spy_conv, spy_wgrad, spy_wino,
+                                                                                                       spy_w43, spy_attn_bwd)
     try:
         loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
         loss.mean().backward()
         torch.cuda.synchronize()
     finally:
-        _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43 = real_conv, real_wgrad, real_wino, real_w43
+        _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43, _hip.attn_bwd = (real_conv, real_wgrad, real_wino,
+                                                                                                           real_w43, real_attn_bwd)
+    # head dim 256: the shipped policy keeps the training step's attention on the three launches; VD_FUSED_ATTN=2 (set by
+    # test_cifar_train_step_b64_fused_attention_hd256 together with the expected count) sends all 18 blocks through the fused backward
+    assert attn_bwd_calls[0] == int(__import__("os").environ.get("VD_EXPECT_FUSED_BWD", "0")), attn_bwd_calls
     code = lambda tr, kt: ((tr * 100 + kt) * 1000 + 128) * 1000 + 128
     if _hip.WINO:           # every residual-block convolution of this network is served by the Winograd kernels
         # 54 forward launches + 54 input gradients, of which the 16 at 32x32 take the F(4x4,3x3) kernel (VD_WINO43=0: none)
@@ -431,6 +441,21 @@ def test_cifar_train_step_b64_vs_oracle():
         worst = max(worst, err / max(ref.norm().item(), 1e-2 * gmax))
         assert err <= 1e-4 * ref.norm().item() + 1e-6 * gmax, f"{k}: rel-L2 {err / max(ref.norm().item(), 1e-30):.3e}"
     print(f"B=64 train step vs oracle: worst per-tensor gradient rel-L2 {worst:.2e}")
+
+
+def test_cifar_train_step_b64_fused_attention_hd256():
+    """the same step with VD_FUSED_ATTN=2: every attention block -- head dim 256, L = 1024 / 256 / 64 -- through the fused forward
+    and the (round 3) fused backward kernels attn_bwd_dq_kernel<256> / attn_bwd_dkv_kernel<256>, which the shipped policy does not
+    pick for training (they are slower than the three-launch path there: _hip.attn_use_fused); against the same oracle"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "--no-header", "-p", "no:cacheprovider",
+                        "-k", "test_cifar_train_step_b64_vs_oracle"], env=dict(os.environ, VD_FUSED_ATTN="2", VD_EXPECT_FUSED_BWD="18"),
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_cifar_train_step_b64_direct_convolutions():
@@ -498,8 +523,10 @@ def test_celeba_train_step_b8_vs_oracle():
         _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43 = real_wino, real_attn, real_w43
     if _hip.WINO:
         assert wino_calls[0] == 2 * 2 * 36, wino_calls            # 36 residual blocks x 2 convolutions x (forward + input gradient), both Winograd orders
-    if _hip.FUSED_ATTN:
-        assert fused[0] == 27, fused                              # every attention block of the merged config (head dim 64)
+    if _hip.FUSED_ATTN != "0":
+        # the merged config's 27 attention blocks (head dim 64): L = 64 x 9, 1024 x 8, 4096 x 1 take the fused backward, the nine
+        # L = 256 blocks the three-launch path (measured policy, _hip.attn_use_fused); VD_FUSED_ATTN=2 forces all 27
+        assert fused[0] == (27 if _hip.FUSED_ATTN == "2" else 18), fused
     torch.set_num_threads(_oracle_threads())
     sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     den = lambda a, b, c: unet_ref.unet_forward(sdo, cfg, a, b, c)

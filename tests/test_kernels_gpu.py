@@ -516,7 +516,7 @@ def test_attn_fused_forward(H, B, nh, L, hd):
     assert torch.equal(o, o2)
 
 
-@pytest.mark.parametrize("B,nh,L,hd", [c for c in ATTN_CASES if c[3] <= 128])
+@pytest.mark.parametrize("B,nh,L,hd", ATTN_CASES + [(2, 1, 1024, 256), (3, 1, 64, 256)])      # (round 3: head dim 256 too)
 def test_attn_fused_backward(H, B, nh, L, hd):
     assert H.attn_supported(L, hd, True)
     hid = nh * hd
@@ -546,7 +546,12 @@ def test_attn_fused_backward(H, B, nh, L, hd):
 
 
 def test_attn_unsupported_shapes_are_refused(H):
-    assert not H.attn_supported(100, 64, False) and not H.attn_supported(256, 32, False) and not H.attn_supported(256, 256, True)
+    assert not H.attn_supported(100, 64, False) and not H.attn_supported(256, 32, False) and not H.attn_supported(256, 512, True)
+    assert H.attn_supported(256, 256, True)             # round 3: the backward kernels are built for head dim 256 as well
+    # which shapes TRAINING takes fused is a measured policy (tests/perf_attn.py), inference always does
+    assert H.attn_use_fused(1024, 256, 256, False) and not H.attn_use_fused(1024, 256, 128, True)
+    assert H.attn_use_fused(4096, 64, 128, True) and not H.attn_use_fused(256, 64, 128, True)
+    assert H.attn_use_fused(4096, 256, 128, True)       # 8.6 GB per materialised map: fused whatever the head dim
     x = torch.zeros(1, 100, 192, device=DEV)
     with pytest.raises(H.HipError):
         H.attn_fwd(x, x, x, 192, x, 192, None, 1, 1, 100, 64, 0.125)

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 
 bool shape_ok(int L, int hd, bool bwd) {
     if (L <= 0 || L % 64) return false;
-    return hd == 64 || hd == 128 || (hd == 256 && !bwd);
+    return hd == 64 || hd == 128 || hd == 256;
 }
 
 }  // namespace
@@ -411,7 +411,7 @@ namespace {
 int attn_bwd_impl(const float* q, const float* k, const float* v, int64_t ld, const float* o, int64_t ldo, const float* dout,
                   int64_t lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int64_t ldd, int32_t B,
                   int32_t nh, int32_t L, int32_t hd, float scale, int phase, void* stream) {
-    VD_REQUIRE(shape_ok(L, hd, true), "vd_attn_bwd: L=%d hd=%d not served (L %% 64 == 0, hd in {64,128})", L, hd);
+    VD_REQUIRE(shape_ok(L, hd, true), "vd_attn_bwd: L=%d hd=%d not served (L %% 64 == 0, hd in {64,128,256})", L, hd);
     VD_REQUIRE(q && k && v && o && dout && lse && delta && dq && dk && dv && B > 0 && nh > 0, "vd_attn_bwd: null operand / empty batch");
     VD_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && ldd % 4 == 0 && vd_aligned16(q) && vd_aligned16(k) && vd_aligned16(v) &&
                vd_aligned16(o) && vd_aligned16(dout) && vd_aligned16(dq) && vd_aligned16(dk) && vd_aligned16(dv) && vd_aligned16(lse) &&
@@ -426,12 +426,14 @@ int attn_bwd_impl(const float* q, const float* k, const float* v, int64_t ld, co
     // phase 1: dQ and delta ; phase 2: dK, dV (needs phase 1's delta) ; 0: both
     if (phase != 2) {
         if (hd == 64) hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, st, a);
+        else if (hd == 128) hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_bwd_dq_kernel<256>, grid, dim3(256), 0, st, a);
         VD_LAUNCH_CHECK("attn_bwd_dq_kernel");
     }
     if (phase != 1) {
         if (hd == 64) hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, st, a);
+        else if (hd == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_bwd_dkv_kernel<256>, grid, dim3(256), 0, st, a);
         VD_LAUNCH_CHECK("attn_bwd_dkv_kernel");
     }
     return 0;

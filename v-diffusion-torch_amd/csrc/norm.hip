@@ -334,6 +334,36 @@ __global__ __launch_bounds__(256) void sum_over_images_kernel(const float* pgb, 
     }
 }
 
+// the same sums for MANY norms in one launch (the per-norm launch is 5 us of latency, 73 times per CIFAR train step):
+// items: 8 x int64 per norm {pgb, dgamma, dbeta, nimg, C, accumulate, -, first block}; a norm takes ceil(C / 16) blocks
+__global__ __launch_bounds__(256) void sum_over_images_batched_kernel(const long long* items, int n) {
+    __shared__ float sh[2][16][17];
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[8 * mid + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* it = items + 8 * lo;
+    const float* pgb = reinterpret_cast<const float*>(it[0]);
+    float* dgamma = reinterpret_cast<float*>(it[1]);
+    float* dbeta = reinterpret_cast<float*>(it[2]);
+    const int nimg = (int)it[3], C = (int)it[4], accumulate = (int)it[5];
+    const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int c = (int)((long long)blockIdx.x - it[7]) * 16 + cx;
+    float a = 0.f, bsum = 0.f;
+    if (c < C)
+        for (int b = ly; b < nimg; b += 16) { a += pgb[((long long)b * 2) * C + c]; bsum += pgb[((long long)b * 2 + 1) * C + c]; }
+    sh[0][ly][cx] = a; sh[1][ly][cx] = bsum;
+    __syncthreads();
+    if (ly == 0 && c < C) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { s0 += sh[0][q][cx]; s1 += sh[1][q][cx]; }
+        dgamma[c] = accumulate ? dgamma[c] + s0 : s0;
+        dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+    }
+}
+
 struct BwdApplyArgs {
     ReduceArgs r; const float* q; const float* add; long long ldadd; float* dx; long long lddx; int accumulate_dx;
 };
@@ -624,12 +654,12 @@ extern "C" int vd_gn_apply(const float* x, int64_t ldx, const float* stats, cons
     return 0;
 }
 
-extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef,
-                               const float* gamma, const float* beta, const float* film, int32_t act, float p_drop,
-                               uint64_t seed, int32_t resample, const float* add, int64_t ldadd, float* dx, int64_t lddx,
-                               int32_t accumulate_dx, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate_params,
-                               int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* ws, size_t ws_bytes,
-                               void* stream) {
+static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef,
+                             const float* gamma, const float* beta, const float* film, int32_t act, float p_drop,
+                             uint64_t seed, int32_t resample, const float* add, int64_t ldadd, float* dx, int64_t lddx,
+                             int32_t accumulate_dx, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate_params,
+                             int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* ws, size_t ws_bytes,
+                             float* pgb_keep, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     VD_REQUIRE(C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "vd_gn_apply_bwd: C/ld must be multiples of 4");
     const int has_norm = gamma != nullptr;
@@ -642,14 +672,16 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
     a.add = add; a.ldadd = ldadd; a.dx = dx; a.lddx = lddx; a.accumulate_dx = accumulate_dx;
     g_last_gn_bwd = has_norm ? -1 : 0;
     if (has_norm) {
-        VD_REQUIRE(x && coef && beta && dgamma && dbeta && C % G == 0 && ldx % 4 == 0, "vd_gn_apply_bwd: missing norm operands");
+        VD_REQUIRE(x && coef && beta && ((dgamma && dbeta) || pgb_keep) && C % G == 0 && ldx % 4 == 0, "vd_gn_apply_bwd: missing norm operands");
         VD_REQUIRE(!film || dfilm, "vd_gn_apply_bwd: film given without dfilm");
         VD_REQUIRE(ws && ws_bytes >= vd_gn_ws_bytes(nimg, (int)HW, C), "vd_gn_apply_bwd: workspace too small");
         const int Cb = pick_cb(C);
         VD_REQUIRE(C % Cb == 0 && Cb % 4 == 0 && Cb <= 1024, "vd_gn_apply_bwd: cannot split C=%d", C);
         float* part = ws;
         float* q = part + (long long)nimg * p.chunks * 2 * C;
-        float* pgb = q + (long long)nimg * 3 * C;
+        // per-image dgamma / dbeta terms: summed over the images right here, or -- pgb_keep -- left in the caller's buffer for ONE
+        // vd_gn_param_sums_batched launch over all norms of the backward pass
+        float* pgb = pgb_keep ? pgb_keep : q + (long long)nimg * 3 * C;
         p.part = part;
         // single-pass form whenever one workgroup can hold an image's slab in registers (<= 8 float4 pairs per thread)
         static const bool two_pass = getenv("VD_GN_TWO_PASS") != nullptr;        // A/B switch for profiling
@@ -667,9 +699,11 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
                 dim3 grid(C / CS, nimg);
                 if (TPB == 1024) launch_fused_bwd<1024>(npt, grid, st, f); else launch_fused_bwd<256>(npt, grid, st, f);
                 VD_LAUNCH_CHECK("gn_bwd_fused_kernel");
-                hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
-                                   accumulate_params);
-                VD_LAUNCH_CHECK("sum_over_images_kernel");
+                if (!pgb_keep) {
+                    hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
+                                       accumulate_params);
+                    VD_LAUNCH_CHECK("sum_over_images_kernel");
+                }
                 return 0;
             }
         }
@@ -678,15 +712,45 @@ extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, in
         hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nimg), dim3(256), (2 * C + 2 * G) * sizeof(float), st, part, p.chunks,
                            coef, gamma, beta, film, C, G, HW, q, dfilm, pgb);
         VD_LAUNCH_CHECK("gn_bwd_finalize_kernel");
-        hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
-                           accumulate_params);
-        VD_LAUNCH_CHECK("sum_over_images_kernel");
+        if (!pgb_keep) {
+            hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
+                               accumulate_params);
+            VD_LAUNCH_CHECK("sum_over_images_kernel");
+        }
         a.q = q;
     }
     const int Cba = pick_cb(C);
     VD_REQUIRE(C % Cba == 0 && Cba % 4 == 0 && Cba <= 1024 && nimg <= 65535, "vd_gn_apply_bwd: cannot split C=%d / nimg=%d", C, nimg);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((HW + APIX - 1) / APIX), nimg, C / Cba), dim3(256), 0, st, a, Cba);
     VD_LAUNCH_CHECK("gn_bwd_apply_kernel");
+    return 0;
+}
+
+extern "C" int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef,
+                               const float* gamma, const float* beta, const float* film, int32_t act, float p_drop,
+                               uint64_t seed, int32_t resample, const float* add, int64_t ldadd, float* dx, int64_t lddx,
+                               int32_t accumulate_dx, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate_params,
+                               int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* ws, size_t ws_bytes,
+                               void* stream) {
+    return gn_apply_bwd_impl(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx, accumulate_dx,
+                             dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, C, G, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int vd_gn_apply_bwd_keep(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* coef,
+                                    const float* gamma, const float* beta, const float* film, int32_t act, float p_drop,
+                                    uint64_t seed, int32_t resample, const float* add, int64_t ldadd, float* dx, int64_t lddx,
+                                    int32_t accumulate_dx, float* dfilm, float* pgb_keep, int32_t nimg, int32_t H, int32_t W,
+                                    int32_t C, int32_t G, float* ws, size_t ws_bytes, void* stream) {
+    VD_REQUIRE(gamma && pgb_keep, "vd_gn_apply_bwd_keep: needs a norm and the [nimg][2][C] buffer for its per-image dgamma / dbeta terms");
+    return gn_apply_bwd_impl(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx, accumulate_dx,
+                             dfilm, nullptr, nullptr, 0, nimg, H, W, C, G, ws, ws_bytes, pgb_keep, stream);
+}
+
+extern "C" int vd_gn_param_sums_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream) {
+    VD_REQUIRE(items_dev && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "vd_gn_param_sums_batched: bad table");
+    hipLaunchKernelGGL(sum_over_images_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(items_dev), n);
+    VD_LAUNCH_CHECK("sum_over_images_batched_kernel");
     return 0;
 }
 

@@ -67,6 +67,9 @@ _SIGNATURES = {
     "vd_gn_apply_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _vp, _i64, _i32,
                                   _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_gn_bwd_last_kernel": (C.c_int, []),
+    "vd_gn_apply_bwd_keep": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _vp, _i64, _i32,
+                                       _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_gn_param_sums_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_colsum_ws_bytes": (_sz, [_i64, _i32]),
     "vd_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "vd_axpby": (C.c_int, [_vp, _i64, _f32, _vp, _i64, _f32, _i64, _i32, _vp]),
@@ -420,14 +423,27 @@ def _gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, 
 
 
 def gn_apply_bwd(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
-                 accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G=32):
+                 accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G=32, pgb_keep=None):
+    """pgb_keep ([nimg][2][Cc] floats): leave the per-image dgamma / dbeta terms there for one gn_param_sums_batched launch over
+    all norms of the backward pass instead of summing them here (dgamma / dbeta are then not touched)"""
     nb = lib().vd_gn_ws_bytes(nimg, H * W, Cc)
     ws = workspace(nb, dy.device, "gn")
     hw_dy = H * W // 4 if resample == RS_DOWN else (H * W * 4 if resample == RS_UP else H * W)
     nbytes = 4.0 * nimg * Cc * (hw_dy + H * W * (1 + (gamma is not None) + (add is not None) + bool(accumulate_dx)))
     with _TimedBytes("gn_apply_bwd", nbytes, rename=_gn_bwd_name):
-        _gn_apply_bwd_call(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
-                           accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G, ws)
+        if pgb_keep is not None:
+            _check(lib().vd_gn_apply_bwd_keep(ptr(dy), lddy, ptr(x), ldx, ptr(coef), ptr(gamma), ptr(beta), ptr(film), int(act),
+                                              float(p_drop), int(seed), resample, ptr(add), ldadd, ptr(dx), lddx, int(accumulate_dx),
+                                              ptr(dfilm), ptr(pgb_keep), nimg, H, W, Cc, G, ws.data_ptr(), ws.numel() * 4, stream()),
+                   "vd_gn_apply_bwd_keep")
+        else:
+            _gn_apply_bwd_call(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
+                               accumulate_dx, dfilm, dgamma, dbeta, accumulate_params, nimg, H, W, Cc, G, ws)
+
+
+def gn_param_sums_batched(table, n, total_blocks):
+    assert table.is_cuda and table.dtype == torch.int64 and table.is_contiguous()
+    _check(lib().vd_gn_param_sums_batched(table.data_ptr(), n, total_blocks, stream()), "vd_gn_param_sums_batched")
 
 
 def _gn_apply_bwd_call(dy, lddy, x, ldx, coef, gamma, beta, film, act, p_drop, seed, resample, add, ldadd, dx, lddx,
@@ -464,11 +480,28 @@ def softmax_rows_bwd(p, dp, rows, L, alpha):
     _check(lib().vd_softmax_rows_bwd(ptr(p), ptr(dp), rows, L, alpha, stream()), "vd_softmax_rows_bwd")
 
 
-FUSED_ATTN = os.environ.get("VD_FUSED_ATTN", "1") != "0"     # A/B switch: 0 keeps the three-launch attention everywhere
+FUSED_ATTN = os.environ.get("VD_FUSED_ATTN", "1")            # A/B switch: 0 = three-launch attention everywhere, 2 = fused wherever served
 
 
 def attn_supported(L, hd, backward):
-    return FUSED_ATTN and bool(lib().vd_attn_supported(L, hd, int(backward)))
+    """is the geometry served by the fused kernels (csrc/attn.hip: L % 64 == 0, head dim 64 / 128 / 256, forward and backward)?"""
+    return FUSED_ATTN != "0" and bool(lib().vd_attn_supported(L, hd, int(backward)))
+
+
+def attn_use_fused(L, hd, rows, training):
+    """Which attention path a block takes.  Inference: the fused forward wherever it is served (faster at every measured shape).
+    Training (forward + backward with recomputation: 9 products where the three-launch path runs 6) by same-box measurement at
+    batch 128 (tests/perf_attn.py, MI355X): head dim 64 fused except at L = 256 (0.144 vs 0.128 ms); head dim 128 / 256 unfused (the
+    backward kernels hold Q/dO or K/V fragments of the whole head dim in registers: one wave per SIMD at head dim 256 -- L = 1024:
+    5.3 vs 3.6 ms) -- unless the materialised [rows, L, L] maps would not be reasonable to keep (>= 4 GiB each), where the fused
+    path is the only sensible one.  VD_FUSED_ATTN=2 forces the fused kernels wherever served (parity tests of the whole step)."""
+    if not attn_supported(L, hd, training):
+        return False
+    if not training or FUSED_ATTN == "2":
+        return True
+    if 4.0 * rows * L * L >= float(1 << 32):
+        return True
+    return hd == 64 and L != 256
 
 
 def attn_fwd(q, k, v, ld, o, ldo, lse, B, nh, L, hd, scale):

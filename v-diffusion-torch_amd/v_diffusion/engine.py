@@ -134,6 +134,9 @@ class UNetEngine:
         self._pack_state = None           # {weight-set key: persistent buffers + device table of the batched weight pack}
         self._last_pack_state = None
         self._packed = None               # {id(weight): (wf, wd)} valid for the weights as of the last forward
+        self._norm_channels = sum(p.numel() for k, p in model.named_parameters()
+                                  if k.endswith(".weight") and p.ndim == 1)          # all GroupNorm weights (the only 1-D weights)
+        self._pgb_arena = self._pgb_table = None
 
     # ------------------------------------------------------------------------------------------ small helpers
     @staticmethod
@@ -166,6 +169,28 @@ class UNetEngine:
             H.gn_stats(x, _ld(x), B, Hh * Ww, C, stats, GROUPS, EPS)
         H.gn_apply(x, _ld(x), stats, gn.weight, gn.bias, film, act, p_drop, seed, rs, y, _ld(y), B, Hh, Ww, C, coef, GROUPS)
         return coef
+
+    # ---- GroupNorm parameter gradients: every norm's backward leaves its per-image dgamma / dbeta terms in a slice of one arena and
+    # ONE launch at the end of backward sums them over the images for all norms (73 five-microsecond launches per CIFAR step before)
+    def _pgb_begin(self, ref, B):
+        need = B * 2 * self._norm_channels
+        if self._pgb_arena is None or self._pgb_arena.numel() < need or self._pgb_arena.device != ref.device:
+            self._pgb_arena = torch.empty(need, dtype=torch.float32, device=ref.device)
+            self._pgb_table = None
+        self._pgb_rows, self._pgb_off, self._pgb_blk = [], 0, 0
+
+    def _pgb(self, B, C, dgamma, dbeta):
+        sl = self._pgb_arena[self._pgb_off: self._pgb_off + B * 2 * C]
+        self._pgb_rows.append([sl.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, C, 0, 0, self._pgb_blk])
+        self._pgb_off += B * 2 * C
+        self._pgb_blk += (C + 15) // 16
+        return sl
+
+    def _pgb_finish(self):
+        key = tuple(tuple(r) for r in self._pgb_rows)
+        if self._pgb_table is None or self._pgb_table[0] != key:            # (flat gradient buffers: built once)
+            self._pgb_table = (key, torch.tensor(self._pgb_rows, dtype=torch.int64).to(self._pgb_arena.device))
+        H.gn_param_sums_batched(self._pgb_table[1], len(self._pgb_rows), self._pgb_blk)
 
     PACK_STATES_MAX = 4       # weight sets (raw / EMA) x (training / inference) whose packed images are kept at a time
 
@@ -485,8 +510,8 @@ class UNetEngine:
         c2, fi = self.film_slot[prefix]
         dfilm = dfilms[c2][fi]
         H.gn_apply_bwd(da2, Cout, h1, Cout, ctx["coef2"], mod.norm2.weight, mod.norm2.bias, film, 1, ctx["p"], ctx["seed"],
-                       H.RS_NONE, None, 0, dh1, Cout, False, dfilm, G[prefix + ".norm2.weight"], G[prefix + ".norm2.bias"], False,
-                       B, Ho, Wo, Cout, GROUPS)
+                       H.RS_NONE, None, 0, dh1, Cout, False, dfilm, None, None, False, B, Ho, Wo, Cout, GROUPS,
+                       pgb_keep=self._pgb(B, Cout, G[prefix + ".norm2.weight"], G[prefix + ".norm2.bias"]))
         del da2
         # conv1
         H.conv3x3_wgrad(a1, Cin, dh1, Cout, B, Ho, Wo, Cin, Cout, G[prefix + ".conv1.weight"], Cin, Cout,
@@ -513,8 +538,8 @@ class UNetEngine:
             addt = dsk
         # norm1 + SiLU (+ resample) and the sum with the skip-path gradient
         H.gn_apply_bwd(da1, Cin, x, ldx, ctx["coef1"], mod.norm1.weight, mod.norm1.bias, None, 1, 0.0, 0, rs, addt, _ld(addt),
-                       dx, _ld(dx), dx_accumulate, None, G[prefix + ".norm1.weight"], G[prefix + ".norm1.bias"], False,
-                       B, Hh, Ww, Cin, GROUPS)
+                       dx, _ld(dx), dx_accumulate, None, None, None, False, B, Hh, Ww, Cin, GROUPS,
+                       pgb_keep=self._pgb(B, Cin, G[prefix + ".norm1.weight"], G[prefix + ".norm1.bias"]))
         # FiLM projection film = fc(ta): weight/bias gradient here (keeps the gradient-completion order); the embedding
         # gradient of all blocks is one batched GEMM at the end of backward (_film_bwd)
         self._linear_bwd(ta, mod.fc.weight, dfilm, G[prefix + ".fc.weight"], G[prefix + ".fc.bias"], None)
@@ -534,9 +559,9 @@ class UNetEngine:
         q, k, v = qkv[0, 0, 0:], qkv[0, 0, hid:], qkv[0, 0, 2 * hid:]
         O = self._new(x, B, L, hid)
         S = lse = None
-        if H.attn_supported(L, hd, tape is not None) and B * nh <= 65535:
+        if B * nh <= 65535 and H.attn_use_fused(L, hd, B * nh, tape is not None):
             # fused kernels (csrc/attn.hip): the [B, nh, L, L] maps never reach HBM; the backward recomputes them from the
-            # per-row log-sum-exp.  (hd = 256 is served forward-only: sampling; its training step keeps the three launches.)
+            # per-row log-sum-exp.  Which shapes take them in training is decided by measurement (_hip.attn_use_fused).
             if tape is not None:
                 lse = self._new(x, B * nh * L)
             H.attn_fwd(q, k, v, ld, O, hid, lse, B, nh, L, hd, alpha)
@@ -596,8 +621,8 @@ class UNetEngine:
         H.gemm(dqkv, mod.proj_in.weight, dxn, M, C, ld, a_kind=H.ROW, b_kind=H.COL, lda=ld, ldb=C, ldc=C)
         # norm (no activation) + the residual branch
         H.gn_apply_bwd(dxn, C, x, ldx, ctx["coef"], mod.norm.weight, mod.norm.bias, None, 0, 0.0, 0, H.RS_NONE, dy, lddy, dx,
-                       _ld(dx), dx_accumulate, None, G[prefix + ".norm.weight"], G[prefix + ".norm.bias"], False, B, Hh, Ww, C,
-                       GROUPS)
+                       _ld(dx), dx_accumulate, None, None, None, False, B, Hh, Ww, C, GROUPS,
+                       pgb_keep=self._pgb(B, C, G[prefix + ".norm.weight"], G[prefix + ".norm.bias"]))
 
     # ------------------------------------------------------------------------------------------ whole network
     def forward(self, x_nchw, t, y, training, save):
@@ -719,6 +744,7 @@ class UNetEngine:
         ta = tape["ta"]
         dta = torch.zeros_like(ta)
         dfilms = {c2: self._new(ta, len(mods), B, c2) for c2, mods in self.film_groups.items()}
+        self._pgb_begin(dout, B)
         # ---- out_conv
         C0 = m.hid_channels * m.ch_multipliers[0]
         gn, conv = m.out_conv[0], m.out_conv[2]
@@ -742,9 +768,10 @@ class UNetEngine:
             H.conv3x3(dout, cop, self._pack_d(conv.weight, cop), None, da, C0, B, H0, W0, cop, C0)
         dh = self._new(dout, B, H0, W0, C0)
         H.gn_apply_bwd(da, C0, o["h"], _ld(o["h"]), o["coef"], gn.weight, gn.bias, None, 1, 0.0, 0, H.RS_NONE, None, 0, dh, C0,
-                       False, None, G["out_conv.0.weight"], G["out_conv.0.bias"], False, B, H0, W0, C0, GROUPS)
+                       False, None, None, None, False, B, H0, W0, C0, GROUPS,
+                       pgb_keep=self._pgb(B, C0, G["out_conv.0.weight"], G["out_conv.0.bias"]))
         del da
-        progress("out_conv.0.bias")
+        progress("out_conv.2.bias")            # (the GroupNorm parameter gradients are finished by ONE launch at the end: _pgb_finish)
         # ---- blocks in reverse
         dskip = {}                     # hs id -> gradient view (written by the consuming up-block)
         dh_cur = dh                    # gradient of the running `h`
@@ -772,7 +799,7 @@ class UNetEngine:
                 del dmid
             else:
                 self._res_bwd(b, b.res, b.prefix, tape[b.prefix], dy, dxbuf, acc, ta, dfilms, G)
-            progress(b.prefix + ".norm.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
+            progress(b.prefix + ".proj_in.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
             if b.kind == "up" and b.consumes:
                 dh_cur = dxbuf[..., :b.ch_h]
                 dskip[b.src_hs] = dxbuf[..., b.ch_h:]
@@ -801,6 +828,7 @@ class UNetEngine:
                       m.in_channels)
             dx = self._new(dout, B, m.in_channels, H0, W0)
             H.nhwc_to_nchw(d4, cip, dx, B, m.in_channels, H0, W0)
+        self._pgb_finish()
         self._film_bwd(dfilms, tape["film_w"], dta)
         self._embed_bwd(tape["embed"], dta, G)
         progress(None)
