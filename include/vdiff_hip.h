@@ -71,6 +71,16 @@ int vd_gemm(const vd_gemm_desc* d, void* stream);
  * epilogue (launches without output statistics); KT = 0 means the register-staged fallback
  * gemm_kernel<BM,BN,a_kind,b_kind,splitk>) */
 int vd_gemm_last_tile(void);
+/* `count` (<= 32) same-shape weight-gradient GEMMs in ONE launch -- the 1x1-convolution / linear weight gradients of the blocks of one
+ * UNet level (autograd of modules.py:79-80,141-144 w.r.t. the weight), whose operands live in unrelated buffers:
+ *   C[e][M][N] (pitch ldc) = A[e]^T B[e],  A[e] = dY [K][M] (pitch lda), B[e] = X [K][N] (pitch ldb)   (= vd_gemm with COL / COL kinds)
+ *   colsum[e][m] = sum_k A[e][k][m]   (the bias gradient; colsum may be NULL)
+ * split-K over `splitk` slabs per entry through ws (vd_gemm_grouped_wgrad_ws_bytes), reduced in a fixed order: bitwise reproducible.
+ * A, B, C, colsum are HOST arrays of device pointers (they travel in the kernel arguments). */
+size_t vd_gemm_grouped_wgrad_ws_bytes(int32_t count, int32_t M, int32_t N, int32_t splitk);
+int vd_gemm_grouped_wgrad(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
+                          int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws, size_t ws_bytes,
+                          void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution, NHWC (replaces F.conv2d at modules.py:141-144 <- unet.py:121,125,217,232).
  *   y[b,y,x,co] = bias[co] + res[b,y,x,co] + sum_{tap,ci} xin[b,y+dy,x+dx,ci] * wpack[co][tap][ci]

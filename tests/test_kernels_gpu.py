@@ -939,3 +939,34 @@ def test_conv3x3_dgrad_wino43_rejects_unsupported(H):
     z = torch.zeros(2, 16, 16, 32, device=DEV)
     with pytest.raises(H.HipError, match="unsupported geometry"):
         H.conv3x3_dgrad_wino43(z, 32, torch.zeros(36 * 32 * 32, device=DEV), torch.empty_like(z), 32, 2, 16, 16, 32, 32)
+
+
+# ------------------------------------------------------------------------------------------------ grouped weight-gradient GEMMs
+@pytest.mark.parametrize("count,M,N,K,splitk,pad", [(3, 64, 96, 1000, 4, 8), (9, 256, 256, 8192, 7, 0), (27, 512, 1024, 128, 1, 0),
+                                                     (2, 768, 256, 4096, 16, 0), (32, 36, 260, 512, 2, 4)])
+def test_gemm_grouped_wgrad(H, count, M, N, K, splitk, pad):
+    """vd_gemm_grouped_wgrad: `count` same-shape dW = dY^T X products (operands in unrelated buffers, row pitches > M / N) and their
+    bias gradients in one launch == the per-entry fp64 products; bitwise reproducible; equal to the single-launch vd_gemm path to
+    rounding.  Reference ops: the weight / bias gradients of modules.py:79-80 (Linear) and :141-144 (1x1 Conv2d)."""
+    g = torch.Generator(DEV).manual_seed(count * 1000 + M)
+    ents, refs = [], []
+    for e in range(count):
+        dy = torch.randn((K, M + pad), device=DEV, generator=g)
+        x = torch.randn((K, N + pad), device=DEV, generator=g)
+        dw = torch.full((M, N + pad), 3.0, device=DEV)
+        db = torch.full((M,), 3.0, device=DEV)
+        ents.append((dy, x, dw, db))
+        refs.append((dy[:, :M].double().T @ x[:, :N].double(), dy[:, :M].double().sum(0)))
+    H.gemm_grouped_wgrad(ents, M, N, K, M + pad, N + pad, N + pad, splitk)
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb) in zip(ents, refs):
+        scale = rw.abs().max().item()
+        assert (dw[:, :N].double() - rw).abs().max().item() <= 2e-6 * scale * max(1.0, (K / 1024) ** 0.5), "grouped dW"
+        assert (db.double() - rb).abs().max().item() <= 2e-6 * max(rb.abs().max().item(), 1.0) * max(1.0, (K / 1024) ** 0.5), "grouped dbias"
+        if pad:
+            assert (dw[:, N:] == 3.0).all(), "padding columns of dW were written"
+    again = [(dy, x, torch.empty_like(dw), torch.empty_like(db)) for dy, x, dw, db in ents]
+    H.gemm_grouped_wgrad(again, M, N, K, M + pad, N + pad, N + pad, splitk)
+    torch.cuda.synchronize()
+    for a, b in zip(ents, again):
+        assert torch.equal(a[2][:, :N], b[2][:, :N]) and torch.equal(a[3], b[3]), "not bitwise reproducible"

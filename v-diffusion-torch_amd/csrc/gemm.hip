@@ -18,6 +18,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +39,7 @@ struct GemmArgs {
                                               // barrier, bit4 = phase timestamps through `colsum`, bit5 = loop-phase cycles through `stats`
     float* stats; int stats_hw;               // GroupNorm partials of the OUTPUT: [img][chunk][2][N], chunk = BM/2 output rows
     long long sBias;                          // bias offset per batch entry zb
+    int group_S;                              // GROUPED launches: split-K slabs per entry
     int lgW, lgHW;                            // log2 of W and H*W when both are powers of two, else -1 (shift/mask instead of divisions)
 };
 
@@ -381,11 +383,21 @@ __device__ __forceinline__ int row_swz_t(int row, int chunk) { return row * KT +
 // quad instead of four consecutive rows of one column: the epilogue writes (and reads residuals) with 16 dwordx4 buffer
 // instructions per wave instead of 64 dword ones.  Used by every launch that does not ask for output statistics (their
 // per-column sums need a column per lane) when N, ldc, ldr are multiples of 4.
-template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR>
+// GROUPED (split-K weight-gradient launches only): blockIdx.z = entry * group_S + slab, and entry e reads its A / B operands from
+// gp.A[e] / gp.B[e] -- up to VD_GROUP_MAX same-shape GEMMs (the 1x1 / linear weight gradients of the blocks of one UNet level, whose
+// operands live in unrelated buffers) in ONE launch instead of one 20-120 us launch each.  The pointer table travels in the kernel
+// arguments; launches that are not grouped carry an empty struct instead.
+constexpr int VD_GROUP_MAX = 32;
+struct GroupPtrs { const float* A[VD_GROUP_MAX]; const float* B[VD_GROUP_MAX]; };
+struct NoGroup {};
+struct GroupOut { float* C[VD_GROUP_MAX]; float* cs[VD_GROUP_MAX]; };
+
+template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED = false>
 #ifndef VD_KT16_BLOCKS
 #define VD_KT16_BLOCKS 4
 #endif
-__global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma_kernel(const GemmArgs p,
+                                                                                          const std::conditional_t<GROUPED, GroupPtrs, NoGroup> gp) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * KT];
     constexpr int MT = BM / 64, NT = BN / 64;
     constexpr int AIT = BM * KT / 1024, BIT = BN * KT / 1024;   // DMA pieces (1 KiB) per wave for A / B
@@ -435,7 +447,14 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
     const float* biasp = p.bias;
     int kt_begin = 0, kt_end = p.kt_total;
     if (SPLITK) {
-        kt_begin = tbz * p.kt_per_split;
+        int slab = tbz;
+        if constexpr (GROUPED) {
+            const int e = tbz / p.group_S;
+            slab = tbz - e * p.group_S;
+            A = gp.A[e];
+            B = gp.B[e];
+        }
+        kt_begin = slab * p.kt_per_split;
         kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
         C += (long long)tbz * p.slab_stride;
     } else {
@@ -921,6 +940,25 @@ __global__ void reduce_slabs_kernel(const float* slabs, int S, long long slab_st
     *o = accumulate ? *o + s : s;
 }
 
+// grouped form: grid.y = entry; entry e sums its S slabs (fixed order) into outs.C[e] and its bias-gradient partials into outs.cs[e]
+__global__ void reduce_slabs_grouped_kernel(const float* slabs, int S, long long slab_stride, int M, int N, const GroupOut outs,
+                                            long long ldo, const float* cpart) {
+    const int e = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* sl = slabs + (long long)e * S * slab_stride;
+    float* cs = outs.cs[e];
+    if (cs && idx < M) {
+        float c = 0.f;
+        for (int z = 0; z < S; ++z) c += cpart[((long long)e * S + z) * M + idx];
+        cs[idx] = c;
+    }
+    if (idx >= (long long)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += sl[z * slab_stride + idx];
+    const int m = idx / N, n = idx % N;
+    outs.C[e][(long long)m * ldo + n] = s;
+}
+
 __global__ void reduce_slabs_oihw_kernel(const float* slabs, int S, long long slab_stride, int Cout, int Cin,
                                          int Cout_w, int Cin_w, float* dw, int accumulate, const float* cpart, float* dbias) {
     // slab element (co, tap*Cin + ci) -> dw[(co*Cin_w + ci)*9 + tap]
@@ -1072,10 +1110,10 @@ void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     const bool tr = use_dma(a) && use_tr(a, BK == VD_IM2COL);
     vd_g_last_tile = ((((tr ? 1 : 0) * 100 + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
-    else if (k16 && tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true>), grid, dim3(256), 0, st, a);
-    else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false>), grid, dim3(256), 0, st, a);
-    else if (tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, false>), grid, dim3(256), 0, st, a);
+    else if (k16 && tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true>), grid, dim3(256), 0, st, a, NoGroup{});
+    else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false>), grid, dim3(256), 0, st, a, NoGroup{});
+    else if (tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, true>), grid, dim3(256), 0, st, a, NoGroup{});
+    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, false>), grid, dim3(256), 0, st, a, NoGroup{});
 }
 
 template <int AK, int BK, bool SPLITK>
@@ -1184,7 +1222,64 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     return 0;
 }
 
+template <int BM, int BN>
+void launch_grouped(const GemmArgs& a, const GroupPtrs& gp, dim3 grid, hipStream_t st) {
+    vd_g_last_tile = ((((1) * 100 + 32) * 1000) + BM) * 1000 + BN;
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, 32, true, true>), grid, dim3(256), 0, st, a, gp);
+}
+
 }  // namespace
+
+/* count same-shape weight-gradient GEMMs in one launch: C[e][M][N] = A[e]^T B[e] (A[e]: [K][M] rows of pitch lda, B[e]: [K][N] rows of
+ * pitch ldb, i.e. vd_gemm with a_kind = b_kind = VD_COL), colsum[e][m] = sum_k A[e][k][m] (or NULL), split-K over `splitk` slabs per
+ * entry through ws, fixed-order reduction (bitwise reproducible).  A / B / C / colsum are HOST arrays of device pointers. */
+extern "C" size_t vd_gemm_grouped_wgrad_ws_bytes(int32_t count, int32_t M, int32_t N, int32_t splitk) {
+    return (size_t)count * (splitk > 1 ? splitk : 1) * ((size_t)M * N + M) * sizeof(float);
+}
+
+extern "C" int vd_gemm_grouped_wgrad(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
+                                     int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws,
+                                     size_t ws_bytes, void* stream) {
+    VD_REQUIRE(A && B && C && count > 0 && count <= VD_GROUP_MAX, "vd_gemm_grouped_wgrad: 1..%d entries (got %d)", VD_GROUP_MAX, count);
+    VD_REQUIRE(M > 0 && N > 0 && K > 0 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc >= N,
+               "vd_gemm_grouped_wgrad: M, N, lda, ldb must be multiples of 4 (M=%d N=%d)", M, N);
+    const int S = splitk > 1 ? splitk : 1;
+    VD_REQUIRE(ws && ws_bytes >= vd_gemm_grouped_wgrad_ws_bytes(count, M, N, S), "vd_gemm_grouped_wgrad: workspace too small");
+    GemmArgs a = {};
+    GroupPtrs gp = {};
+    GroupOut go = {};
+    for (int e = 0; e < count; ++e) {
+        VD_REQUIRE(A[e] && B[e] && C[e] && vd_aligned16(A[e]) && vd_aligned16(B[e]), "vd_gemm_grouped_wgrad: entry %d: null / unaligned operand", e);
+        gp.A[e] = A[e]; gp.B[e] = B[e]; go.C[e] = C[e]; go.cs[e] = colsum ? colsum[e] : nullptr;
+    }
+    a.A = A[0]; a.B = B[0];
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N; a.ldr = 0; a.nh = 1;
+    a.alpha = 1.f; a.lgW = a.lgHW = -1; a.probe = 0;
+    VD_REQUIRE(use_dma(a), "vd_gemm_grouped_wgrad: operands outside the LDS-DMA kernel's range (alignment / row pitch)");
+    const int tile = choose_tile(M, N, false, (long long)count * S, 0);
+    const int tbm = TILES[tile].bm, tbn = TILES[tile].bn;
+    const long long nm = (M + tbm - 1) / tbm, nn = (N + tbn - 1) / tbn;
+    a.kt_total = (K + 31) / 32;
+    a.kt_per_split = (a.kt_total + S - 1) / S;
+    const int used = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;      // slabs that hold work (<= S)
+    a.group_S = used;
+    a.slab_stride = (long long)M * N;
+    a.C = ws;
+    float* cpart = ws + (long long)count * used * a.slab_stride;
+    a.colsum = colsum ? cpart : nullptr;
+    const dim3 grid((unsigned)nn, (unsigned)nm, (unsigned)(count * used));
+    hipStream_t st = (hipStream_t)stream;
+    if (tile == 0) launch_grouped<128, 128>(a, gp, grid, st);
+    else if (tile == 1) launch_grouped<128, 64>(a, gp, grid, st);
+    else if (tile == 2) launch_grouped<64, 128>(a, gp, grid, st);
+    else launch_grouped<64, 64>(a, gp, grid, st);
+    VD_LAUNCH_CHECK("gemm_dma_kernel(grouped)");
+    const long long tot = (long long)M * N;
+    hipLaunchKernelGGL(reduce_slabs_grouped_kernel, dim3((unsigned)((tot + 255) / 256), (unsigned)count), dim3(256), 0, st, ws, used,
+                       a.slab_stride, M, N, go, (long long)ldc, cpart);
+    VD_LAUNCH_CHECK("reduce_slabs_grouped_kernel");
+    return 0;
+}
 
 thread_local int vd_g_last_tile = 0;
 extern "C" int vd_gemm_last_tile(void) { return vd_g_last_tile; }

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "vd_last_error": (C.c_char_p, []),
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_last_tile": (C.c_int, []),
+    "vd_gemm_grouped_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "vd_gemm_grouped_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vd_conv3x3_wino_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64]),
     "vd_conv3x3_wino": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -228,6 +230,25 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
     with _Timed("gemm_dma_kernel<{tile}, " + f"{a_kind}, {b_kind}, " + ("true, {kt}>" if splitk > 1 else "false, {kt}>"),
                 2.0 * M * N * K * batch):
         _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
+
+
+GROUP_MAX = 32
+GROUPED_WGRAD = os.environ.get("VD_GROUPED_WGRAD", "1") != "0"   # A/B switch: 0 = one launch per weight-gradient GEMM
+
+
+def gemm_grouped_wgrad(entries, M, N, K, lda, ldb, ldc, splitk):
+    """entries: [(A = dY rows [K][M], B = X rows [K][N], C = dW [M][N], colsum = dbias [M] or None)], at most GROUP_MAX, all of one shape:
+    C = A^T B (+ colsum) for every entry in ONE launch (vd_gemm_grouped_wgrad)"""
+    n = len(entries)
+    assert 0 < n <= GROUP_MAX
+    arr = lambda i: (_vp * n)(*[ptr(e[i]) for e in entries])
+    has_cs = entries[0][3] is not None
+    assert all((e[3] is not None) == has_cs for e in entries)
+    S = max(1, int(splitk))
+    ws = workspace(lib().vd_gemm_grouped_wgrad_ws_bytes(n, M, N, S), entries[0][0].device, "splitk")
+    with _Timed("gemm_dma_kernel<{tile}, 1, 1, true, 32, true, true>", 2.0 * M * N * K * n):
+        _check(lib().vd_gemm_grouped_wgrad(arr(0), arr(1), arr(2), arr(3) if has_cs else None, n, M, N, K, lda, ldb, ldc, S,
+                                           ws.data_ptr(), ws.numel() * 4, stream()), "vd_gemm_grouped_wgrad")
 
 
 def last_row_tile():

@@ -137,6 +137,7 @@ class UNetEngine:
         self._norm_channels = sum(p.numel() for k, p in model.named_parameters()
                                   if k.endswith(".weight") and p.ndim == 1)          # all GroupNorm weights (the only 1-D weights)
         self._pgb_arena = self._pgb_table = None
+        self._wq = None                   # {shape key: [(dY, X, dW, dbias)]} of deferred weight-gradient GEMMs (inside backward only)
 
     # ------------------------------------------------------------------------------------------ small helpers
     @staticmethod
@@ -169,6 +170,35 @@ class UNetEngine:
             H.gn_stats(x, _ld(x), B, Hh * Ww, C, stats, GROUPS, EPS)
         H.gn_apply(x, _ld(x), stats, gn.weight, gn.bias, film, act, p_drop, seed, rs, y, _ld(y), B, Hh, Ww, C, coef, GROUPS)
         return coef
+
+    # ---- 1x1-convolution / linear weight gradients dW = dY^T X (skip, proj_in, proj_out, fc): nothing downstream in backward
+    # depends on them, so they are queued per shape and run as ONE grouped launch per shape at the end of a UNet level
+    # (vd_gemm_grouped_wgrad) instead of one short split-K GEMM + one slab reduction per block.  The queue keeps the operands alive.
+    def _wgrad(self, dy, x, dw, db, M, N, K, lda, ldb, ldc):
+        if self._wq is None or not H.GROUPED_WGRAD:
+            H.gemm(dy, x, dw, M, N, K, a_kind=H.COL, b_kind=H.COL, lda=lda, ldb=ldb, ldc=ldc, splitk=_splitk(M, N, K), colsum=db)
+            return
+        key = (M, N, K, lda, ldb, ldc, db is not None)
+        q = self._wq.setdefault(key, [])
+        q.append((dy, x, dw, db))
+        if len(q) == H.GROUP_MAX:
+            self._wgrad_flush_key(key)
+
+    def _wgrad_flush_key(self, key):
+        q = self._wq.pop(key, None)
+        if not q:
+            return
+        M, N, K, lda, ldb, ldc, _ = key
+        if len(q) == 1 or M % 4 or N % 4:
+            for dy, x, dw, db in q:
+                H.gemm(dy, x, dw, M, N, K, a_kind=H.COL, b_kind=H.COL, lda=lda, ldb=ldb, ldc=ldc, splitk=_splitk(M, N, K), colsum=db)
+            return
+        tiles = ((M + 63) // 64) * ((N + 63) // 64) * len(q)
+        H.gemm_grouped_wgrad(q, M, N, K, lda, ldb, ldc, max(1, min(64, 1024 // max(tiles, 1), K // 256)))
+
+    def _wgrad_flush(self):
+        for key in list(self._wq or {}):
+            self._wgrad_flush_key(key)
 
     # ---- GroupNorm parameter gradients: every norm's backward leaves its per-image dgamma / dbeta terms in a slice of one arena and
     # ONE launch at the end of backward sums them over the images for all norms (73 five-microsecond launches per CIFAR step before)
@@ -354,13 +384,11 @@ class UNetEngine:
         H.gemm(x, w, out, M, N, K, a_kind=H.ROW, b_kind=H.ROW, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=b,
                accumulate=accumulate)
 
-    @staticmethod
-    def _linear_bwd(x, w, dy, dw, db, dx, dx_accumulate=False):
+    def _linear_bwd(self, x, w, dy, dw, db, dx, dx_accumulate=False):
         """dw[N,K] = dy^T x ; db[N] = colsum(dy) ; dx[M,K] (+)= dy @ w"""
         M, K = x.shape
         N = w.shape[0]
-        H.gemm(dy, x, dw, N, K, M, a_kind=H.COL, b_kind=H.COL, lda=dy.stride(0), ldb=x.stride(0), ldc=K, splitk=_splitk(N, K, M),
-               colsum=db)                                          # db = column sums of dy, from the same staged tiles
+        self._wgrad(dy, x, dw, db, N, K, M, dy.stride(0), x.stride(0), K)      # db = column sums of dy, from the same staged tiles
         if dx is not None:
             H.gemm(dy, w, dx, M, K, N, a_kind=H.ROW, b_kind=H.COL, lda=dy.stride(0), ldb=w.stride(0), ldc=dx.stride(0),
                    accumulate=dx_accumulate)
@@ -524,8 +552,7 @@ class UNetEngine:
             xs = ctx["xs"]
             P = B * Ho * Wo
             w = mod.skip.weight
-            H.gemm(dy, xs, G[prefix + ".skip.weight"], Cout, Cin, P, a_kind=H.COL, b_kind=H.COL, lda=lddy, ldb=_ld(xs), ldc=Cin,
-                   splitk=_splitk(Cout, Cin, P), colsum=G[prefix + ".skip.bias"])
+            self._wgrad(dy, xs, G[prefix + ".skip.weight"], G[prefix + ".skip.bias"], Cout, Cin, P, lddy, _ld(xs), Cin)
             dsk = self._new(x, B, Ho, Wo, Cin)
             H.gemm(dy, w, dsk, P, Cin, Cout, a_kind=H.ROW, b_kind=H.COL, lda=lddy, ldb=Cin, ldc=Cin)
         else:
@@ -590,8 +617,7 @@ class UNetEngine:
         hid, ld = nh * hd, 3 * nh * hd
         M = B * L
         # proj_out
-        H.gemm(dy, O, G[prefix + ".proj_out.weight"], C, hid, M, a_kind=H.COL, b_kind=H.COL, lda=lddy, ldb=hid, ldc=hid,
-               splitk=_splitk(C, hid, M), colsum=G[prefix + ".proj_out.bias"])
+        self._wgrad(dy, O, G[prefix + ".proj_out.weight"], G[prefix + ".proj_out.bias"], C, hid, M, lddy, hid, hid)
         dO = self._new(x, B, L, hid)
         H.gemm(dy, mod.proj_out.weight, dO, M, hid, C, a_kind=H.ROW, b_kind=H.COL, lda=lddy, ldb=hid, ldc=hid)
         dqkv = self._new(x, B, L, ld)
@@ -615,8 +641,7 @@ class UNetEngine:
             del dP
         del dO
         # proj_in
-        H.gemm(dqkv, xn, G[prefix + ".proj_in.weight"], ld, C, M, a_kind=H.COL, b_kind=H.COL, lda=ld, ldb=C, ldc=C,
-               splitk=_splitk(ld, C, M), colsum=G[prefix + ".proj_in.bias"])
+        self._wgrad(dqkv, xn, G[prefix + ".proj_in.weight"], G[prefix + ".proj_in.bias"], ld, C, M, ld, C, C)
         dxn = self._new(x, B, Hh, Ww, C)
         H.gemm(dqkv, mod.proj_in.weight, dxn, M, C, ld, a_kind=H.ROW, b_kind=H.COL, lda=ld, ldb=C, ldc=C)
         # norm (no activation) + the residual branch
@@ -745,6 +770,7 @@ class UNetEngine:
         dta = torch.zeros_like(ta)
         dfilms = {c2: self._new(ta, len(mods), B, c2) for c2, mods in self.film_groups.items()}
         self._pgb_begin(dout, B)
+        self._wq = {}
         # ---- out_conv
         C0 = m.hid_channels * m.ch_multipliers[0]
         gn, conv = m.out_conv[0], m.out_conv[2]
@@ -799,7 +825,13 @@ class UNetEngine:
                 del dmid
             else:
                 self._res_bwd(b, b.res, b.prefix, tape[b.prefix], dy, dxbuf, acc, ta, dfilms, G)
-            progress(b.prefix + ".proj_in.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
+            # the deferred weight-gradient GEMMs of a level run when backward leaves it; only then is everything up to this
+            # block's last tensor final (gradient-bucket overlap: trainer.GradReducer.ready)
+            nxt = self.plan[bi - 1] if bi > 0 else None
+            grp = lambda q: (q.level, "mid" if q.kind.startswith("mid") else q.kind)
+            if nxt is None or grp(nxt) != grp(b):
+                self._wgrad_flush()
+                progress(b.prefix + ".proj_in.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
             if b.kind == "up" and b.consumes:
                 dh_cur = dxbuf[..., :b.ch_h]
                 dskip[b.src_hs] = dxbuf[..., b.ch_h:]
@@ -831,6 +863,8 @@ class UNetEngine:
         self._pgb_finish()
         self._film_bwd(dfilms, tape["film_w"], dta)
         self._embed_bwd(tape["embed"], dta, G)
+        self._wgrad_flush()
+        self._wq = None
         progress(None)
         return dx
 
