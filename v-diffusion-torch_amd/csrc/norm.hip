@@ -25,6 +25,20 @@ struct ReduceArgs {
     float* part;                          // [nimg][chunks][2][C]
 };
 
+// upstream gradient g (already gathered at the forward input's resolution) -> gradient wrt the pre-activation z: dropout mask, SiLU'
+__device__ __forceinline__ f32x4 dz_finish(const ReduceArgs& p, f32x4 g, f32x4 xv, f32x4 sc, f32x4 of, unsigned long long vec_index) {
+    if (p.p_drop > 0.f) g *= vd_dropout_scale4(p.seed, vec_index, p.p_drop);
+    if (p.act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = xv[j] * sc[j] + of[j];
+            const float s = vd_sigmoid(z);
+            g[j] *= s * (1.f + z * (1.f - s));
+        }
+    }
+    return g;
+}
+
 // gradient wrt the pre-activation z of one float4 of the forward input (pixel `pix` of an H x W image)
 __device__ __forceinline__ f32x4 dz_of(const ReduceArgs& p, const float* dy_img, int pix, int c4, f32x4 xv, f32x4 sc,
                                        f32x4 of, unsigned long long vec_index) {
@@ -43,16 +57,7 @@ __device__ __forceinline__ f32x4 dz_of(const ReduceArgs& p, const float* dy_img,
                 *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy) + *reinterpret_cast<const f32x4*>(b0 + Wo * p.lddy + p.lddy);
         }
     }
-    if (p.p_drop > 0.f) g *= vd_dropout_scale4(p.seed, vec_index, p.p_drop);
-    if (p.act) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float z = xv[j] * sc[j] + of[j];
-            const float s = vd_sigmoid(z);
-            g[j] *= s * (1.f + z * (1.f - s));
-        }
-    }
-    return g;
+    return dz_finish(p, g, xv, sc, of, vec_index);
 }
 
 template <int MODE>
@@ -79,6 +84,27 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const ReduceArgs p, in
             }
             const long long HWo = p.resample == VD_RS_DOWN ? p.HW / 4 : (p.resample == VD_RS_UP ? p.HW * 4 : p.HW);
             const float* dimg = p.dy + (long long)b * HWo * p.lddy;
+            if (p.resample == VD_RS_NONE) {
+                // four pixels per trip, their eight loads in flight together (one load pair per trip left the pass latency-bound)
+                for (int i = r; i < np; i += 4 * rows) {
+                    f32x4 xv[4], g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int pix = (int)pix0 + min(i + u * rows, np - 1);
+                        xv[u] = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
+                        g[u] = *reinterpret_cast<const f32x4*>(dimg + (long long)pix * p.lddy + c4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i + u * rows < np) {
+                            const int pix = (int)pix0 + i + u * rows;
+                            const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * (p.C >> 2) + (c4 >> 2);
+                            const f32x4 dz = dz_finish(p, g[u], xv[u], sc, of, vi);
+                            a0 += dz;
+                            a1 += dz * (xv[u] * nr + nm);
+                        }
+                }
+            } else
             for (int i = r; i < np; i += rows) {
                 const int pix = (int)pix0 + i;
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
@@ -395,6 +421,32 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const BwdApplyArgs a,
     const float* aimg = a.add ? a.add + (long long)b * p.HW * a.ldadd : nullptr;
     float* oimg = a.dx + (long long)b * p.HW * a.lddx;
     const int vtot = p.C >> 2;
+    if (p.resample == VD_RS_NONE && p.has_norm) {
+        // (the second pass of the two-pass form, 64x64 images) four pixels per trip, all their loads in flight together
+        for (int i = r; i < np; i += 4 * rows) {
+            f32x4 xv[4], g[4], ad[4], od[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pix = p0 + min(i + u * rows, np - 1);
+                xv[u] = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
+                g[u] = *reinterpret_cast<const f32x4*>(dimg + (long long)pix * p.lddy + c4);
+                if (aimg) ad[u] = *reinterpret_cast<const f32x4*>(aimg + (long long)pix * a.ldadd + c4);
+                if (a.accumulate_dx) od[u] = *reinterpret_cast<const f32x4*>(oimg + (long long)pix * a.lddx + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * rows < np) {
+                    const int pix = p0 + i + u * rows;
+                    const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
+                    f32x4 d = dz_finish(p, g[u], xv[u], sc, of, vi);
+                    d = q0 * d - q1 - (xv[u] * nr + nm) * q2;
+                    if (aimg) d += ad[u];
+                    if (a.accumulate_dx) d += od[u];
+                    *reinterpret_cast<f32x4*>(oimg + (long long)pix * a.lddx + c4) = d;
+                }
+        }
+        return;
+    }
     for (int i = r; i < np; i += rows) {
         const int pix = p0 + i;
         f32x4 xv = {0.f, 0.f, 0.f, 0.f};
@@ -448,20 +500,51 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     const int vtot = C >> 2;
     f32x4 xv[NREG], dz[NPT];
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (p.resample == VD_RS_NONE) {
+        // the common case (every norm but the four resampling blocks): ALL 2 NPT loads of the thread are issued before the first
+        // value is used (the per-pixel form waited on every pair: the resample kind is a run-time value, so the compiler kept each
+        // pixel's loads behind its branches).  Measured: no change (107 us at 32x32x256 either way) -- sixteen waves per CU already
+        // covered the latency; what holds this kernel at 3.8 TB/s is the 128-byte segment per pixel row of a 32-channel slab (64-byte
+        // slabs: -25 %), and starting half of the first round late so that load and store phases of different CUs interleave
+        // changes nothing either (-2 % ... +10 %).  Rows beyond the image are clamped (loaded twice, masked below).
+        f32x4 xin[NPT];
+        if (act) {
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-        const int pix = r + i * rows;
-        f32x4 xh = a0 * 0.f;
-        dz[i] = xh;
-        if (act && pix < HW) {
-            const f32x4 xin = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
-            const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
-            dz[i] = dz_of(p, dimg, pix, c4, xin, sc, of, vi);
-            xh = xin * nr + nm;                             // keep x_hat: all the second half needs
-            a0 += dz[i];
-            a1 += dz[i] * xh;
+            for (int i = 0; i < NPT; ++i) {
+                const int pc = min(r + i * rows, HW - 1);
+                xin[i] = *reinterpret_cast<const f32x4*>(ximg + (long long)pc * p.ldx + c4);
+                dz[i] = *reinterpret_cast<const f32x4*>(dimg + (long long)pc * p.lddy + c4);
+            }
         }
-        if (i < NREG) xv[i] = xh; else xl[i - NREG][tid] = xh;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int pix = r + i * rows;
+            f32x4 xh = a0 * 0.f;
+            if (act && pix < HW) {
+                const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
+                dz[i] = dz_finish(p, dz[i], xin[i], sc, of, vi);
+                xh = xin[i] * nr + nm;                      // keep x_hat: all the second half needs
+                a0 += dz[i];
+                a1 += dz[i] * xh;
+            } else dz[i] = xh;
+            if (i < NREG) xv[i] = xh; else xl[i - NREG][tid] = xh;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int pix = r + i * rows;
+            f32x4 xh = a0 * 0.f;
+            dz[i] = xh;
+            if (act && pix < HW) {
+                const f32x4 xin = *reinterpret_cast<const f32x4*>(ximg + (long long)pix * p.ldx + c4);
+                const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
+                dz[i] = dz_of(p, dimg, pix, c4, xin, sc, of, vi);
+                xh = xin * nr + nm;
+                a0 += dz[i];
+                a1 += dz[i] * xh;
+            }
+            if (i < NREG) xv[i] = xh; else xl[i - NREG][tid] = xh;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[tid][j] = act ? a0[j] : 0.f; red[tid][4 + j] = act ? a1[j] : 0.f; }
@@ -521,16 +604,30 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     }
     const float* aimg = f.a.add ? f.a.add + (long long)b * p.HW * f.a.ldadd : nullptr;
     float* oimg = f.a.dx + (long long)b * p.HW * f.a.lddx;
+    // dx = q0 dz - q1 - x_hat q2 (in place in dz), then the skip-path gradient / the running dx, every load of a kind in flight at once
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const f32x4 xh = i < NREG ? xv[i < NREG ? i : 0] : xl[i < NREG ? 0 : i - NREG][tid];
+        dz[i] = q0 * dz[i] - q1 - xh * q2;
+    }
+    if (aimg) {
+        f32x4 ad[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) ad[i] = *reinterpret_cast<const f32x4*>(aimg + (long long)min(r + i * rows, HW - 1) * f.a.ldadd + c4);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) dz[i] += ad[i];
+    }
+    if (f.a.accumulate_dx) {
+        f32x4 od[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) od[i] = *reinterpret_cast<const f32x4*>(oimg + (long long)min(r + i * rows, HW - 1) * f.a.lddx + c4);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) dz[i] += od[i];
+    }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int pix = r + i * rows;
-        if (pix >= HW) continue;
-        const f32x4 xh = i < NREG ? xv[i < NREG ? i : 0] : xl[i < NREG ? 0 : i - NREG][tid];
-        f32x4 d = q0 * dz[i] - q1 - xh * q2;
-        if (aimg) d += *reinterpret_cast<const f32x4*>(aimg + (long long)pix * f.a.ldadd + c4);
-        float* o = oimg + (long long)pix * f.a.lddx + c4;
-        if (f.a.accumulate_dx) d += *reinterpret_cast<const f32x4*>(o);
-        *reinterpret_cast<f32x4*>(o) = d;
+        if (pix < HW) *reinterpret_cast<f32x4*>(oimg + (long long)pix * f.a.lddx + c4) = dz[i];
     }
 }
 
