@@ -71,13 +71,15 @@ int vd_gemm(const vd_gemm_desc* d, void* stream);
  * epilogue (launches without output statistics); KT = 0 means the register-staged fallback
  * gemm_kernel<BM,BN,a_kind,b_kind,splitk>) */
 int vd_gemm_last_tile(void);
-/* `count` (<= 32) same-shape weight-gradient GEMMs in ONE launch -- the 1x1-convolution / linear weight gradients of the blocks of one
+/* `count` (<= 36) same-shape weight-gradient GEMMs in ONE launch -- the 1x1-convolution / linear weight gradients of the blocks of one
  * UNet level (autograd of modules.py:79-80,141-144 w.r.t. the weight), whose operands live in unrelated buffers:
  *   C[e][M][N] (pitch ldc) = A[e]^T B[e],  A[e] = dY [K][M] (pitch lda), B[e] = X [K][N] (pitch ldb)   (= vd_gemm with COL / COL kinds)
  *   colsum[e][m] = sum_k A[e][k][m]   (the bias gradient; colsum may be NULL)
  * split-K over `splitk` slabs per entry through ws (vd_gemm_grouped_wgrad_ws_bytes), reduced in a fixed order: bitwise reproducible.
  * A, B, C, colsum are HOST arrays of device pointers (they travel in the kernel arguments). */
 size_t vd_gemm_grouped_wgrad_ws_bytes(int32_t count, int32_t M, int32_t N, int32_t splitk);
+/* slab count in [min_slabs, max_slabs] that fills whole residency rounds of the device best (>= 8 K tiles per slab) */
+int vd_gemm_grouped_wgrad_auto_split(int32_t count, int32_t M, int32_t N, int32_t K, int32_t min_slabs, int32_t max_slabs);
 int vd_gemm_grouped_wgrad(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
                           int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws, size_t ws_bytes,
                           void* stream);
@@ -145,6 +147,21 @@ int vd_wino43_last_kernel(void);
 int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, void* stream);
 /* all tensors in one launch: items_dev = [n][8] int64 {w, U43, 0, Cout, Cin, 0, 0, first block}; a tensor takes (Cin/32)*(Cout/8) blocks */
 int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
+/* weight (and bias) gradient of the same convolution through F(4x4,3x3), UNFUSED: one HBM-bound pass writes dM = A dY A^T and V = B^T d B
+ * ([36][tiles][channels], 2.25x the size of dY / x each), the 36 GEMMs over the tile index run as one vd_gemm_grouped_wgrad launch (1.78x fewer
+ * MFMA cycles than vd_conv3x3_wgrad_wino), a small kernel folds G^T . G into OIHW; the bias gradient is the column sum of plane (1,1).
+ * Same arguments and result as vd_conv3x3_wgrad_wino (accumulate, padded dims, deterministic).  _supported: H, W, Cin, Cout multiples
+ * of 4, at least 1024 tiles of 4x4 outputs.  _phase: 1 = transforms, 2 = GEMMs (+ slab reduction), 4 = finish (per-kernel timing). */
+int vd_conv3x3_wgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t lddy);
+size_t vd_conv3x3_wgrad_wino43_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int vd_conv3x3_wgrad_wino43(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                            int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                            int32_t accumulate, float* ws, size_t ws_bytes, void* stream);
+int vd_conv3x3_wgrad_wino43_phase(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                                  int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                                  int32_t accumulate, float* ws, size_t ws_bytes, int32_t phase, void* stream);
+/* split-K slabs per plane of the calling thread's last vd_conv3x3_wgrad_wino43 launch (test / profiling aid) */
+int vd_wino43_wgrad_last_kernel(void);
 
 /* all 3x3 kernels of a network in one launch: items_dev = [n][8] int64 {w, uf, ud, Cout, Cin, tiled, 0, first 256-thread block};
  * tiled = 1 (Cout, Cin multiples of 16): the tensor takes (Cout/16)*(Cin/16) blocks of one 16x16 tile, else ceil(Cout*Cin/256) */

@@ -286,7 +286,7 @@ def test_wino_conv_at_bench_launches(H, case):
 
 @pytest.mark.parametrize("case", WINO_BENCH, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}to{c[4]}")
 def test_wino_wgrad_at_bench_launches(H, case):
-    """vd_conv3x3_wgrad_wino (what H.conv3x3_wgrad routes to when VD_WINO is on) at the bench launches: weight + bias gradient vs
+    """vd_conv3x3_wgrad_wino (the fused F(2x2,3x3) weight gradient) at the bench launches: weight + bias gradient vs
     fp64 on the device, bitwise reproducible, instantiation wino_wgrad_kernel<TWS, true> asserted through its own launcher's code"""
     nimg, Hh, Ww, Cin, Cout, _ = case
     x = F.silu(_rand((nimg, Hh, Ww, Cin), 7))
@@ -295,7 +295,9 @@ def test_wino_wgrad_at_bench_launches(H, case):
     db = torch.full((Cout,), 3.0, device=DEV)
     assert H.WINO and H.lib().vd_conv3x3_wgrad_wino_supported(nimg, Hh, Ww, Cin, Cout, Cin, Cout)
     tile_before = H.lib().vd_gemm_last_tile()
-    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
+    # (called directly: H.conv3x3_wgrad routes the large layers to the F(4x4,3x3) path since round 3 -- test_wino43_wgrad_at_bench_launches;
+    #  this kernel is what the 8x8 layers, small batches and VD_WINO43_WGRAD=0 run)
+    H.conv3x3_wgrad_wino(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
     k = H.lib().vd_wino_wgrad_last_kernel()
     tws, slabs, dbias = k // 2000, (k // 2) % 1000, k & 1
     assert (tws, dbias) == (min(Ww // 2, 16), 1) and slabs >= 1, (tws, slabs, dbias)
@@ -303,7 +305,7 @@ def test_wino_wgrad_at_bench_launches(H, case):
     assert blocks * slabs >= 0.9 * NCU, f"{blocks} blocks x {slabs} slabs leave more than a tenth of the CUs idle"
     assert H.lib().vd_gemm_last_tile() == tile_before, "the Winograd weight gradient must not touch vd_gemm_last_tile"
     dw2 = torch.empty_like(dw)
-    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=None)
+    H.conv3x3_wgrad_wino(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=None)
     assert H.lib().vd_wino_wgrad_last_kernel() == k - 1                       # same plan, bias-free instantiation
     torch.cuda.synchronize()
     assert torch.equal(dw, dw2), "weight gradient is not bitwise reproducible"
@@ -348,6 +350,40 @@ def test_wino43_dgrad_at_bench_launches(H, case):
     print(f"wino43 dgrad {case[:5]}: rel-L2 {rel:.2e}, max err {err:.2e} of {sc:.2f}")
 
 
+@pytest.mark.parametrize("case", [c for c in WINO_BENCH if c[1] >= 16], ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}to{c[4]}")
+def test_wino43_wgrad_at_bench_launches(H, case):
+    """The weight (+ bias) gradient H.conv3x3_wgrad runs for the 16x16 ... 64x64 layers at B = 128 since round 3: F(4x4,3x3), unfused
+    (vd_conv3x3_wgrad_wino43: transforms -> 36 grouped split-K GEMMs -> finish).  Against fp64 on the device; the stated bound on gradients
+    is relative L2 <= 1e-4, the path is held to 8e-6 (measured 1.6-3.4e-6; the fused F(2x2,3x3) kernel: 0.7-2e-6) and 4e-5 of the
+    largest element; bitwise reproducible; accumulate mode; the routing is asserted through the path's own launcher code."""
+    nimg, Hh, Ww, Cin, Cout, _ = case
+    x = F.silu(_rand((nimg, Hh, Ww, Cin), 7))
+    dy = _rand((nimg, Hh, Ww, Cout), 8, 0.05)
+    dw = torch.full((Cout, Cin, 3, 3), 3.0, device=DEV)
+    db = torch.full((Cout,), 3.0, device=DEV)
+    assert H.wgrad43_supported(nimg, Hh, Ww, Cin, Cout, Cin, Cout)
+    w2_before = H.lib().vd_wino_wgrad_last_kernel()
+    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
+    S = H.lib().vd_wino43_wgrad_last_kernel()
+    T = nimg * (Hh // 4) * (Ww // 4)
+    assert S >= 1 and T / S <= 1536 + 1 or S == 24, (S, T)           # fp32 accumulation chains of at most ~1536 tiles
+    assert H.lib().vd_wino_wgrad_last_kernel() == w2_before, "routed to the F(2x2,3x3) kernel"
+    dw2 = torch.empty_like(dw)
+    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=None)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2), "weight gradient is not bitwise reproducible"
+    ref, xp, d2 = _wgrad_fp64_gpu(x, dy)
+    rel = ((dw.double() - ref).norm() / ref.norm()).item()
+    err = (dw.double() - ref).abs().max().item()
+    assert rel <= 8e-6 and err <= 4e-5 * ref.abs().max().item(), f"wgrad43 rel-L2 {rel:.3e}, max err {err:.3e} of {ref.abs().max().item():.2f}"
+    dbr = d2.sum(0)
+    assert (db.double() - dbr).abs().max().item() <= 2e-5 * max(dbr.abs().max().item(), 1.0)
+    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=db, accumulate=True)      # dw2 = 2 dw, db = 2 db
+    torch.cuda.synchronize()
+    assert (dw2 - 2 * dw).abs().max().item() <= 1e-6 * dw.abs().max().item() and (db.double() - 2 * dbr).abs().max().item() <= 4e-5 * max(dbr.abs().max().item(), 1.0)
+    print(f"wino43 wgrad {case[:5]} slabs={S}: rel-L2 {rel:.2e}, max err {err:.2e} of {ref.abs().max().item():.2f}")
+
+
 def test_cifar_train_step_b64_vs_oracle():
     """One full CIFAR-cond train-step forward/backward at B = 64 (every 32x32 conv launch has 512+ row tiles x 2 column tiles
     = the KT = 16 forms; the 32x32 weight gradients see 65536 pixels = the wide split-K form) against the CPU oracle on the
@@ -383,7 +419,9 @@ def test_cifar_train_step_b64_vs_oracle():
         g0, w0 = orig(), _hip.lib().vd_wino_wgrad_last_kernel()
         r = real_wgrad(*a, **k)
         # which launcher ran is read from the one it writes: the Winograd weight gradient leaves vd_gemm_last_tile alone
-        if _hip.WINO and _hip.lib().vd_conv3x3_wgrad_wino_supported(*[a[i] for i in (4, 5, 6, 7, 8)], a[1], a[3]):
+        if _hip.wgrad43_supported(*[a[i] for i in (4, 5, 6, 7, 8)], a[1], a[3]):
+            seen.add(("wgrad_wino43", a[5]))                                               # image height
+        elif _hip.WINO and _hip.lib().vd_conv3x3_wgrad_wino_supported(*[a[i] for i in (4, 5, 6, 7, 8)], a[1], a[3]):
             seen.add(("wgrad_wino", _hip.lib().vd_wino_wgrad_last_kernel() // 2000))       # TWS
         else:
             seen.add(("wgrad", orig()))
@@ -421,7 +459,9 @@ def test_cifar_train_step_b64_vs_oracle():
         # 54 forward launches + 54 input gradients, of which the 16 at 32x32 take the F(4x4,3x3) kernel (VD_WINO43=0: none)
         n43 = 16 if _hip.WINO43 else 0
         assert (wino_calls[0], w43_calls[0]) == (108 - n43, n43) and not any(k == "conv" for k, _ in seen), (wino_calls, w43_calls, sorted(seen))
-        assert {k for k in seen if k[0] == "wgrad_wino"} == {("wgrad_wino", 16), ("wgrad_wino", 8), ("wgrad_wino", 4)}, sorted(seen)
+        # B = 64: the 32x32 layers (4096 tiles) take the F(4x4,3x3) weight gradient, 16x16 (1024 tiles) and 8x8 the fused F(2x2,3x3) kernel
+        want = {("wgrad_wino43", 32), ("wgrad_wino", 8), ("wgrad_wino", 4)} if _hip.WINO43_WGRAD else {("wgrad_wino", 16), ("wgrad_wino", 8), ("wgrad_wino", 4)}
+        assert {k for k in seen if k[0].startswith("wgrad_wino")} == want, sorted(seen)
         assert not any(k == "wgrad" for k, _ in seen), sorted(seen)
     else:                   # VD_WINO=0 (test_cifar_train_step_b64_direct_convolutions): the direct implicit-GEMM forms
         assert ("conv", code(0, 16)) in seen and ("conv", code(1, 16)) in seen and wino_calls[0] == 0 and w43_calls[0] == 0, sorted(seen)

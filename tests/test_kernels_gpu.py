@@ -970,3 +970,51 @@ def test_gemm_grouped_wgrad(H, count, M, N, K, splitk, pad):
     torch.cuda.synchronize()
     for a, b in zip(ents, again):
         assert torch.equal(a[2][:, :N], b[2][:, :N]) and torch.equal(a[3], b[3]), "not bitwise reproducible"
+
+
+# ------------------------------------------------------------------------------------------------ F(4x4,3x3) weight gradient (unfused)
+WGRAD43_CASES = [  # nimg, H, W, Cin, Cout, Cin_w, Cout_w, ldx_extra, lddy_extra
+    (16, 32, 32, 32, 64, 32, 64, 0, 0),        # 1024 tiles: the smallest served problem
+    (9, 64, 32, 48, 36, 48, 36, 16, 12),       # non-square, channel counts off the tile sizes, ld > C on both sides
+    (64, 16, 16, 96, 32, 96, 32, 0, 0),        # 16x16 images
+    (20, 32, 32, 4, 32, 3, 32, 0, 0), (20, 32, 32, 32, 4, 32, 3, 0, 0),      # padded thin sides
+    (4, 64, 64, 192, 192, 192, 192, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD43_CASES)
+def test_conv3x3_wgrad_wino43(H, case):
+    """vd_conv3x3_wgrad_wino43 == autograd of F.conv2d with respect to the kernel and the bias (fp64 truth), bitwise reproducible,
+    accumulate mode, padded dims.  Bounds: relative L2 8e-6, 4e-5 of the largest element (the stated bound on gradients is 1e-4)."""
+    nimg, Hh, Ww, Cin, Cout, Cin_w, Cout_w, ex, ey = case
+    assert H.lib().vd_conv3x3_wgrad_wino43_supported(nimg, Hh, Ww, Cin, Cout, Cin + ex, Cout + ey) == 1
+    x = torch.zeros(nimg, Cin, Hh, Ww)
+    x[:, :Cin_w] = rnd(nimg, Cin_w, Hh, Ww, seed=1)
+    dy = torch.zeros(nimg, Cout, Hh, Ww)
+    dy[:, :Cout_w] = rnd(nimg, Cout_w, Hh, Ww, seed=2)
+    w64 = torch.zeros(Cout_w, Cin_w, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[:, :Cin_w].double(), w64, padding=1).backward(dy[:, :Cout_w].double())
+    dw = torch.ones(Cout_w, Cin_w, 3, 3, device=DEV)
+    db = torch.ones(Cout_w, device=DEV)
+    xd, dyd = nhwc(x, Cin + ex), nhwc(dy, Cout + ey)
+    H.conv3x3_wgrad_wino43(xd, Cin + ex, dyd, Cout + ey, nimg, Hh, Ww, Cin, Cout, dw, Cin_w, Cout_w, accumulate=True, dbias=db)
+    torch.cuda.synchronize()
+    ref = w64.grad
+    got = dw.double().cpu() - 1.0
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel <= 8e-6 and (got - ref).abs().max().item() <= 4e-5 * ref.abs().max().item(), f"wgrad43 rel-L2 {rel:.3e}"
+    dbr = dy[:, :Cout_w].double().sum((0, 2, 3))
+    assert (db.double().cpu() - 1.0 - dbr).abs().max().item() <= 2e-5 * max(dbr.abs().max().item(), 1.0)
+    a, b = torch.empty_like(dw), torch.empty_like(dw)
+    H.conv3x3_wgrad_wino43(xd, Cin + ex, dyd, Cout + ey, nimg, Hh, Ww, Cin, Cout, a, Cin_w, Cout_w)
+    H.conv3x3_wgrad_wino43(xd, Cin + ex, dyd, Cout + ey, nimg, Hh, Ww, Cin, Cout, b, Cin_w, Cout_w)
+    assert torch.equal(a, b), "not bitwise reproducible"
+    assert ((a.double().cpu() - ref).norm() / ref.norm()).item() <= 8e-6
+
+
+def test_conv3x3_wgrad_wino43_rejects_unsupported(H):
+    f = H.lib().vd_conv3x3_wgrad_wino43_supported
+    assert f(4, 32, 32, 32, 32, 32, 32) == 0             # 256 tiles: too few (the fused F(2x2,3x3) kernel is faster)
+    assert f(16, 30, 32, 32, 32, 32, 32) == 0            # H % 4
+    assert f(16, 32, 32, 30, 32, 32, 32) == 0            # Cin % 4
+    assert f(16, 32, 32, 32, 32, 32, 32) == 1

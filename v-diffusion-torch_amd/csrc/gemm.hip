@@ -387,7 +387,7 @@ __device__ __forceinline__ int row_swz_t(int row, int chunk) { return row * KT +
 // gp.A[e] / gp.B[e] -- up to VD_GROUP_MAX same-shape GEMMs (the 1x1 / linear weight gradients of the blocks of one UNet level, whose
 // operands live in unrelated buffers) in ONE launch instead of one 20-120 us launch each.  The pointer table travels in the kernel
 // arguments; launches that are not grouped carry an empty struct instead.
-constexpr int VD_GROUP_MAX = 32;
+constexpr int VD_GROUP_MAX = 36;      // (36: the xi planes of the F(4x4,3x3) weight gradient, wino43.hip)
 struct GroupPtrs { const float* A[VD_GROUP_MAX]; const float* B[VD_GROUP_MAX]; };
 struct NoGroup {};
 struct GroupOut { float* C[VD_GROUP_MAX]; float* cs[VD_GROUP_MAX]; };
@@ -1222,17 +1222,42 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
     return 0;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int KTV = 32>
 void launch_grouped(const GemmArgs& a, const GroupPtrs& gp, dim3 grid, hipStream_t st) {
-    vd_g_last_tile = ((((1) * 100 + 32) * 1000) + BM) * 1000 + BN;
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, 32, true, true>), grid, dim3(256), 0, st, a, gp);
+    vd_g_last_tile = ((((1) * 100 + KTV) * 1000) + BM) * 1000 + BN;
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, KTV, true, true>), grid, dim3(256), 0, st, a, gp);
 }
+// 128x128 tiles of a grouped launch with at least this many workgroups take the KT = 16 form (32 KB of LDS: four workgroups per CU)
+constexpr long long GROUPED_K16_MIN_WGS = 768;
 
 }  // namespace
 
 /* count same-shape weight-gradient GEMMs in one launch: C[e][M][N] = A[e]^T B[e] (A[e]: [K][M] rows of pitch lda, B[e]: [K][N] rows of
  * pitch ldb, i.e. vd_gemm with a_kind = b_kind = VD_COL), colsum[e][m] = sum_k A[e][k][m] (or NULL), split-K over `splitk` slabs per
  * entry through ws, fixed-order reduction (bitwise reproducible).  A / B / C / colsum are HOST arrays of device pointers. */
+/* split-K slab count for vd_gemm_grouped_wgrad that fills whole residency rounds of the device best (all workgroups do equal work and
+ * `per_cu` of them fit a CU, so a launch runs in rounds of CUs x per_cu: 576 workgroups on 512 slots take two rounds for 1.125 rounds of
+ * work), with at least min_slabs slabs (shorter fp32 accumulation chains: the caller's accuracy budget) and at most max_slabs. */
+extern "C" int vd_gemm_grouped_wgrad_auto_split(int32_t count, int32_t M, int32_t N, int32_t K, int32_t min_slabs, int32_t max_slabs) {
+    const int tile = choose_tile(M, N, false, (long long)count * 8, 0);
+    const long long blocks = (long long)((M + TILES[tile].bm - 1) / TILES[tile].bm) * ((N + TILES[tile].bn - 1) / TILES[tile].bn) * count;
+    // (128x128 tiles: long launches run the KT = 16 form, four workgroups per CU)
+    const long long slots = (long long)vd_cu_count() * (tile == 0 && blocks * (min_slabs > 1 ? min_slabs : 1) >= GROUPED_K16_MIN_WGS / 2 ? 4 : TILES[tile].per_cu);
+    int lo = min_slabs > 1 ? min_slabs : 1, hi = max_slabs > lo ? max_slabs : lo;
+    const int kmax = K / 256 > 1 ? K / 256 : 1;                       // at least 8 K tiles per slab
+    if (hi > kmax) hi = kmax;
+    if (lo > hi) lo = hi;
+    int best = lo;
+    double best_eff = -1.0;
+    for (int s = lo; s <= hi; ++s) {
+        const long long wgs = blocks * s, rounds = (wgs + slots - 1) / slots;
+        double eff = (double)wgs / (double)(rounds * slots);
+        eff *= 1.0 - 0.004 * s;                                       // mild preference for fewer slabs (less reduction traffic)
+        if (eff > best_eff) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+
 extern "C" size_t vd_gemm_grouped_wgrad_ws_bytes(int32_t count, int32_t M, int32_t N, int32_t splitk) {
     return (size_t)count * (splitk > 1 ? splitk : 1) * ((size_t)M * N + M) * sizeof(float);
 }
@@ -1259,7 +1284,8 @@ extern "C" int vd_gemm_grouped_wgrad(const float* const* A, const float* const* 
     const int tile = choose_tile(M, N, false, (long long)count * S, 0);
     const int tbm = TILES[tile].bm, tbn = TILES[tile].bn;
     const long long nm = (M + tbm - 1) / tbm, nn = (N + tbn - 1) / tbn;
-    a.kt_total = (K + 31) / 32;
+    const bool k16 = tile == 0 && nm * nn * count * S >= GROUPED_K16_MIN_WGS;
+    a.kt_total = k16 ? (K + 15) / 16 : (K + 31) / 32;
     a.kt_per_split = (a.kt_total + S - 1) / S;
     const int used = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;      // slabs that hold work (<= S)
     a.group_S = used;
@@ -1269,7 +1295,8 @@ extern "C" int vd_gemm_grouped_wgrad(const float* const* A, const float* const* 
     a.colsum = colsum ? cpart : nullptr;
     const dim3 grid((unsigned)nn, (unsigned)nm, (unsigned)(count * used));
     hipStream_t st = (hipStream_t)stream;
-    if (tile == 0) launch_grouped<128, 128>(a, gp, grid, st);
+    if (tile == 0 && k16) launch_grouped<128, 128, 16>(a, gp, grid, st);
+    else if (tile == 0) launch_grouped<128, 128>(a, gp, grid, st);
     else if (tile == 1) launch_grouped<128, 64>(a, gp, grid, st);
     else if (tile == 2) launch_grouped<64, 128>(a, gp, grid, st);
     else launch_grouped<64, 64>(a, gp, grid, st);

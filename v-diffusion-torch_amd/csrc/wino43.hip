@@ -429,7 +429,167 @@ __global__ __launch_bounds__(256) void wino43_pack_batched_kernel(const long lon
                 (int)((long long)blockIdx.x - it[7]));
 }
 
+// ==================================================================================================================
+// WEIGHT GRADIENT in the F(4x4,3x3) domain, unfused (round 3):
+//   dU[xi][co][ci] = sum_t dM[xi][t][co] V[xi][t][ci],   dM = A dY_t A^T (4x4 -> 6x6),  V = B^T d_t B (6x6 patch),   dw = G^T dU G
+// 36 GEMMs whose K index is the 4x4-output tile: 1.78x fewer MFMA cycles than the F(2x2,3x3) weight gradient of wino.hip.  Unlike
+// the input gradient, BOTH MFMA operands are transformed per tile here, and a fused kernel cannot amortise those transforms inside
+// 160 KB of LDS.  So the transforms run as ONE HBM-bound pass that writes dM and V ([xi][tile][channel], 2.25x
+// the size of dY / x each) and the 36 GEMMs run on the plain tile engine as one grouped split-K launch (vd_gemm_grouped_wgrad);
+// a last small kernel folds G^T . G and transposes to OIHW.  The bias gradient rides on the GEMMs too: their column sums give
+// sum_t dM[xi][t][co], and a fixed combination of those planes is the sum over all pixels of dY (finish kernel).
+// ==================================================================================================================
+// The weight gradient uses the interpolation points {0, +-3/4, +-3/2, inf} instead of the input gradient's {0, +-1, +-2, inf}: its
+// GEMMs accumulate thousands of tile products per fp32 chain, and with the smaller transform coefficients of these points the
+// relative L2 error of dw is half of what the classic points give (simulated with sequential fp32 chains and measured: DESIGN.md);
+// every coefficient of B^T and A is a dyadic rational (exact in fp32), the /81 and /243 of G appear only in the finish kernel.
+//   B^T = [81/64 0 -45/16 0 1 0 ; 0 -27/16 -9/4 3/4 1 0 ; 0 27/16 -9/4 -3/4 1 0 ; 0 -27/32 -9/16 3/2 1 0 ; 0 27/32 -9/16 -3/2 1 0 ; 0 81/64 0 -45/16 0 1]
+__device__ __forceinline__ void bt6(const f32x4 (&d)[6], f32x4 (&o)[6]) {
+    const f32x4 e1 = d[4] - 2.25f * d[2], f1 = 0.75f * d[3] - 1.6875f * d[1];
+    const f32x4 e2 = d[4] - 0.5625f * d[2], f2 = 1.5f * d[3] - 0.84375f * d[1];
+    o[0] = 1.265625f * d[0] + (d[4] - 2.8125f * d[2]);
+    o[1] = e1 + f1;
+    o[2] = e1 - f1;
+    o[3] = e2 + f2;
+    o[4] = e2 - f2;
+    o[5] = 1.265625f * d[1] + (d[5] - 2.8125f * d[3]);
+}
+// A = (A^T)^T, 6 x 4:  rows [1 0 0 0 ; 1 3/4 9/16 27/64 ; 1 -3/4 9/16 -27/64 ; 1 3/2 9/4 27/8 ; 1 -3/2 9/4 -27/8 ; 0 0 0 1]
+__device__ __forceinline__ void a6(const f32x4 (&y)[4], f32x4 (&o)[6]) {
+    const f32x4 e1 = y[0] + 0.5625f * y[2], f1 = 0.75f * y[1] + 0.421875f * y[3];
+    const f32x4 e2 = y[0] + 2.25f * y[2], f2 = 1.5f * y[1] + 3.375f * y[3];
+    o[0] = y[0];
+    o[1] = e1 + f1;
+    o[2] = e1 - f1;
+    o[3] = e2 + f2;
+    o[4] = e2 - f2;
+    o[5] = y[3];
+}
+
+struct WgT43 {
+    const float* x; long long ldx; const float* dy; long long lddy;
+    float* V; float* dM;                       // [36][T][Cin], [36][T][Cout]
+    int nimg, H, W, Cin, Cout, TW, TPI, T;     // tiles per row / image / in all
+};
+
+// block (64 channel quads, 4 tiles); grid (ceil(max(Cin, Cout) / 256), T / 4, 2): z = 0 transforms the input patches, z = 1 the gradients
+__global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43 p) {
+    const int quad = blockIdx.x * 64 + threadIdx.x, tile = blockIdx.y * 4 + threadIdx.y;
+    if (tile >= p.T) return;
+    const int img = tile / p.TPI, tin = tile - img * p.TPI;
+    const int ty = tin / p.TW, tx = tin - ty * p.TW;
+    const int c4 = 4 * quad;
+    if (blockIdx.z == 0) {
+        if (c4 >= p.Cin) return;
+        f32x4 R[6][6];
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+            const int yy = 4 * ty - 1 + pr;
+            f32x4 d[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int xx = 4 * tx - 1 + q;
+                d[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                    d[q] = *reinterpret_cast<const f32x4*>(p.x + ((long long)(img * p.H + yy) * p.W + xx) * p.ldx + c4);
+            }
+            bt6(d, R[pr]);                                          // along the row: R[pr][b] = sum_q B^T[b][q] d[pr][q]
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            f32x4 col[6], o[6];
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) col[pr] = R[pr][b];
+            bt6(col, o);                                            // V[a][b] = sum_p B^T[a][p] R[p][b]
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                *reinterpret_cast<f32x4*>(p.V + ((long long)(6 * a + b) * p.T + tile) * p.Cin + c4) = o[a];
+        }
+    } else {
+        if (c4 >= p.Cout) return;
+        f32x4 R[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 y[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                y[v] = *reinterpret_cast<const f32x4*>(p.dy + ((long long)(img * p.H + 4 * ty + u) * p.W + 4 * tx + v) * p.lddy + c4);
+            a6(y, R[u]);                                            // R[u][b] = sum_v A[b][v] dY[u][v]
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const f32x4 col[4] = {R[0][b], R[1][b], R[2][b], R[3][b]};
+            f32x4 o[6];
+            a6(col, o);                                             // dM[a][b] = sum_u A[a][u] R[u][b]
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                *reinterpret_cast<f32x4*>(p.dM + ((long long)(6 * a + b) * p.T + tile) * p.Cout + c4) = o[a];
+        }
+    }
+}
+
+// dw[co][ci][3][3] (+)= G^T dU[.][co][ci] G       G^T = [64/81 -128/243 -128/243 32/243 32/243 0 ; 0 -32/81 32/81 16/81 -16/81 0 ; 0 -8/27 -8/27 8/27 8/27 1]
+// dbias[co] (+)= sum_ab p_a p_b cs[6a+b][co] with A^T p = (1,1,1,1): p = (-1/9, 8/9, 0, 2/9, 0, -1/8), i.e. sum over ALL pixels of dY
+// recovered from the column sums of the dM planes that ride on the GEMMs (fp64: a few hundred values)
+__global__ __launch_bounds__(256) void wino43_wgrad_finish_kernel(const float* dU, const float* cs, int Cout, int Cin, int Cout_w, int Cin_w,
+                                                                  float* dw, float* dbias, int accumulate) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dbias && idx < Cout_w) {
+        const double pv[6] = {-1.0 / 9, 8.0 / 9, 0.0, 2.0 / 9, 0.0, -1.0 / 8};
+        double c = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                if (pv[a] != 0.0 && pv[b] != 0.0) c += pv[a] * pv[b] * (double)cs[(long long)(6 * a + b) * Cout + idx];
+        dbias[idx] = accumulate ? dbias[idx] + (float)c : (float)c;
+    }
+    if (idx >= (long long)Cout * Cin) return;
+    const int co = (int)(idx / Cin), ci = (int)(idx - (long long)co * Cin);
+    if (co >= Cout_w || ci >= Cin_w) return;
+    float u[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) u[a][b] = dU[(long long)(6 * a + b) * Cout * Cin + idx];
+    constexpr float g0 = 64.f / 81, g12 = 128.f / 243, g34 = 32.f / 243, h12 = 32.f / 81, h34 = 16.f / 81, k = 8.f / 27;
+    float t[3][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const float s12 = u[1][b] + u[2][b], d12 = u[2][b] - u[1][b], s34 = u[3][b] + u[4][b], d34 = u[3][b] - u[4][b];
+        t[0][b] = g0 * u[0][b] - g12 * s12 + g34 * s34;
+        t[1][b] = h12 * d12 + h34 * d34;
+        t[2][b] = k * (s34 - s12) + u[5][b];
+    }
+    float* o = dw + ((long long)co * Cin_w + ci) * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float s12 = t[r][1] + t[r][2], d12 = t[r][2] - t[r][1], s34 = t[r][3] + t[r][4], d34 = t[r][3] - t[r][4];
+        const float w0 = g0 * t[r][0] - g12 * s12 + g34 * s34;
+        const float w1 = h12 * d12 + h34 * d34;
+        const float w2 = k * (s34 - s12) + t[r][5];
+        o[3 * r] = accumulate ? o[3 * r] + w0 : w0;
+        o[3 * r + 1] = accumulate ? o[3 * r + 1] + w1 : w1;
+        o[3 * r + 2] = accumulate ? o[3 * r + 2] + w2 : w2;
+    }
+}
+
+struct Wg43Plan { bool ok; int T, S; size_t v_f, m_f, u_f, cs_f, gemm_bytes; };
+Wg43Plan wg43_plan(int nimg, int H, int W, int Cin, int Cout) {
+    Wg43Plan g = {};
+    if (nimg <= 0 || H % 4 || W % 4 || H < 4 || W < 4 || Cin % 4 || Cout % 4) return g;
+    g.T = nimg * (H / 4) * (W / 4);
+    // split-K slabs: whole residency rounds of the chip (vd_gemm_grouped_wgrad_auto_split), fp32 accumulation chains of at most ~1536
+    // tiles (the error of dw grows with the chain length), at most 24 slabs
+    g.S = vd_gemm_grouped_wgrad_auto_split(36, Cout, Cin, g.T, (g.T + 1535) / 1536, 24);
+    g.v_f = (size_t)36 * g.T * Cin; g.m_f = (size_t)36 * g.T * Cout; g.u_f = (size_t)36 * Cout * Cin; g.cs_f = (size_t)36 * Cout;
+    g.gemm_bytes = vd_gemm_grouped_wgrad_ws_bytes(36, Cout, Cin, g.S);
+    g.ok = true;
+    return g;
+}
+
 thread_local int g_last43 = 0;
+thread_local int g_last43w = 0;        // split-K slabs of the calling thread's last vd_conv3x3_wgrad_wino43 launch
 
 }  // namespace
 
@@ -489,3 +649,80 @@ extern "C" int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64
     VD_LAUNCH_CHECK("wino43_pack_batched_kernel");
     return 0;
 }
+
+/* ---- weight (and bias) gradient of the 3x3 convolution through F(4x4,3x3), unfused: same arguments and result as vd_conv3x3_wgrad_wino.
+ * Serves H, W multiples of 4 and Cin, Cout multiples of 4; _supported additionally requires at least 1024 tiles (below that the
+ * F(2x2,3x3) kernel is faster) and tensors below 2 GiB. */
+extern "C" int vd_conv3x3_wgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t lddy) {
+    const Wg43Plan g = wg43_plan(nimg, H, W, Cin, Cout);
+    if (!g.ok || ldx % 4 || lddy % 4 || g.T < 1024 || g.T % 4) return 0;
+    const long long px = (long long)nimg * H * W, lim = 0x7FFFFFF0LL / 4;
+    if (px * ldx >= lim || px * lddy >= lim) return 0;
+    if ((long long)g.T * (Cin > Cout ? Cin : Cout) * 4 >= (1LL << 40)) return 0;
+    return 1;
+}
+
+extern "C" size_t vd_conv3x3_wgrad_wino43_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    const Wg43Plan g = wg43_plan(nimg, H, W, Cin, Cout);
+    if (!g.ok) return 0;
+    return (g.v_f + g.m_f + g.u_f + g.cs_f) * sizeof(float) + g.gemm_bytes;
+}
+
+/* phases (per-kernel timing): 1 = transforms, 2 = the 36 grouped GEMMs, 4 = finish; 7 = all */
+static int wgrad43_impl(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W, int32_t Cin,
+                        int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w, int32_t accumulate, float* ws,
+                        size_t ws_bytes, void* stream, int phases) {
+    VD_REQUIRE(xin && dy && dw_oihw && ws, "vd_conv3x3_wgrad_wino43: null operand");
+    VD_REQUIRE(vd_conv3x3_wgrad_wino43_supported(nimg, H, W, Cin, Cout, ldx, lddy),
+               "vd_conv3x3_wgrad_wino43: unsupported geometry nimg=%d H=%d W=%d Cin=%d Cout=%d", nimg, H, W, Cin, Cout);
+    VD_REQUIRE(Cin_w <= Cin && Cout_w <= Cout, "vd_conv3x3_wgrad_wino43: real dims exceed padded dims");
+    VD_REQUIRE(vd_aligned16(xin) && vd_aligned16(dy) && vd_aligned16(ws), "vd_conv3x3_wgrad_wino43: operands must be 16-byte aligned");
+    VD_REQUIRE(ws_bytes >= vd_conv3x3_wgrad_wino43_ws_bytes(nimg, H, W, Cin, Cout), "vd_conv3x3_wgrad_wino43: workspace too small");
+    const Wg43Plan g = wg43_plan(nimg, H, W, Cin, Cout);
+    float* V = ws;
+    float* dM = V + g.v_f;
+    float* dU = dM + g.m_f;
+    float* cs = dU + g.u_f;
+    float* gws = cs + g.cs_f;
+    hipStream_t st = (hipStream_t)stream;
+    if (phases & 1) {
+        WgT43 t = {};
+        t.x = xin; t.ldx = ldx; t.dy = dy; t.lddy = lddy; t.V = V; t.dM = dM;
+        t.nimg = nimg; t.H = H; t.W = W; t.Cin = Cin; t.Cout = Cout; t.TW = W / 4; t.TPI = (H / 4) * (W / 4); t.T = g.T;
+        const int cmax = Cin > Cout ? Cin : Cout;
+        hipLaunchKernelGGL(wino43_wgrad_transform_kernel, dim3((unsigned)((cmax + 255) / 256), (unsigned)(g.T / 4), 2), dim3(64, 4), 0, st, t);
+        VD_LAUNCH_CHECK("wino43_wgrad_transform_kernel");
+    }
+    if (phases & 2) {
+        const float* A[36]; const float* B[36]; float* C[36]; float* colsum[36];
+        for (int e = 0; e < 36; ++e) {
+            A[e] = dM + (size_t)e * g.T * Cout; B[e] = V + (size_t)e * g.T * Cin; C[e] = dU + (size_t)e * Cout * Cin; colsum[e] = cs + (size_t)e * Cout;
+        }
+        const int rc = vd_gemm_grouped_wgrad(A, B, C, colsum, 36, Cout, Cin, g.T, Cout, Cin, Cin, g.S, gws, g.gemm_bytes, stream);
+        if (rc) return rc;
+        g_last43w = g.S;
+    }
+    if (phases & 4) {
+        const long long tot = (long long)Cout * Cin;
+        hipLaunchKernelGGL(wino43_wgrad_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dU, cs, Cout, Cin, Cout_w, Cin_w,
+                           dw_oihw, dbias, accumulate);
+        VD_LAUNCH_CHECK("wino43_wgrad_finish_kernel");
+    }
+    return 0;
+}
+
+extern "C" int vd_conv3x3_wgrad_wino43(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,
+                                       int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w,
+                                       int32_t accumulate, float* ws, size_t ws_bytes, void* stream) {
+    return wgrad43_impl(xin, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw_oihw, dbias, Cin_w, Cout_w, accumulate, ws, ws_bytes, stream, 7);
+}
+
+extern "C" int vd_conv3x3_wgrad_wino43_phase(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
+                                             int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w,
+                                             int32_t Cout_w, int32_t accumulate, float* ws, size_t ws_bytes, int32_t phase, void* stream) {
+    VD_REQUIRE(phase == 1 || phase == 2 || phase == 4, "vd_conv3x3_wgrad_wino43_phase: phase must be 1 (transforms), 2 (GEMMs) or 4 (finish)");
+    return wgrad43_impl(xin, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw_oihw, dbias, Cin_w, Cout_w, accumulate, ws, ws_bytes, stream, phase);
+}
+
+/* split-K slabs per xi plane of the calling thread's last vd_conv3x3_wgrad_wino43 launch (0: none yet) -- test / profiling aid */
+extern "C" int vd_wino43_wgrad_last_kernel(void) { return g_last43w; }

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_last_tile": (C.c_int, []),
     "vd_gemm_grouped_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "vd_gemm_grouped_wgrad_auto_split": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "vd_gemm_grouped_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "vd_conv3x3": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vd_conv3x3_wino_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64]),
@@ -56,6 +57,11 @@ _SIGNATURES = {
     "vd_wino43_last_kernel": (C.c_int, []),
     "vd_wino43_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "vd_wino43_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
+    "vd_conv3x3_wgrad_wino43_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64]),
+    "vd_conv3x3_wgrad_wino43_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "vd_conv3x3_wgrad_wino43": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "vd_wino43_wgrad_last_kernel": (C.c_int, []),
+    "vd_conv3x3_wgrad_wino43_phase": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _i32, _vp]),
     "vd_gn_stats_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_gn_coef_from_partials": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "vd_conv3x3_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
@@ -232,7 +238,7 @@ def gemm(A, B, Cm, M, N, K, *, a_kind=ROW, b_kind=ROW, lda, ldb, ldc, bias=None,
         _check(lib().vd_gemm(C.byref(d), stream()), "vd_gemm")
 
 
-GROUP_MAX = 32
+GROUP_MAX = 36
 GROUPED_WGRAD = os.environ.get("VD_GROUPED_WGRAD", "1") != "0"   # A/B switch: 0 = one launch per weight-gradient GEMM
 
 
@@ -352,9 +358,37 @@ def conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_
         _check(lib().vd_conv3x3_wgrad_wino_phase(*args, 2, stream()), "vd_conv3x3_wgrad_wino_phase")
 
 
+WINO43_WGRAD = os.environ.get("VD_WINO43_WGRAD", "1") != "0"   # A/B switch: 0 keeps every weight gradient on F(2x2,3x3)
+WINO43_WGRAD_MIN_TILES = int(os.environ.get("VD_WINO43_WGRAD_MIN_TILES", "2048"))   # (16x16 at batch 128: x1.2; below, the fused F(2x2,3x3) kernel is as fast)
+
+
+def wgrad43_supported(nimg, H, W, Cin, Cout, ldx, lddy):
+    return (WINO and WINO43_WGRAD and nimg * (H // 4) * (W // 4) >= WINO43_WGRAD_MIN_TILES
+            and bool(lib().vd_conv3x3_wgrad_wino43_supported(nimg, H, W, Cin, Cout, ldx, lddy)))
+
+
+def conv3x3_wgrad_wino43(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None):
+    """F(4x4,3x3) weight gradient, unfused (vd_conv3x3_wgrad_wino43): transforms -> 36 grouped GEMMs -> finish"""
+    nb = lib().vd_conv3x3_wgrad_wino43_ws_bytes(nimg, H, W, Cin, Cout)
+    ws = workspace(nb, x.device, "wgrad43")
+    args = (ptr(x), ldx, ptr(dy), lddy, nimg, H, W, Cin, Cout, ptr(dw), ptr(dbias), Cin_w, Cout_w, int(accumulate), ws.data_ptr(),
+            ws.numel() * 4)
+    if PROFILE is None:
+        _check(lib().vd_conv3x3_wgrad_wino43(*args, stream()), "vd_conv3x3_wgrad_wino43")
+        return
+    with _TimedBytes("wino43_wgrad_transform_kernel", 4.0 * nimg * H * W * (Cin + Cout) * (1 + 2.25)):
+        _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 1, stream()), "vd_conv3x3_wgrad_wino43_phase")
+    with _TimedName("wino43_wgrad_gemm (gemm_dma_kernel<..., grouped> x 36 planes)", 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 2, stream()), "vd_conv3x3_wgrad_wino43_phase")
+    with _TimedName("wino43_wgrad_finish_kernel", 0.0):
+        _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 4, stream()), "vd_conv3x3_wgrad_wino43_phase")
+
+
 def conv3x3_wgrad(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate=False, dbias=None, direct=False):
-    """weight (and bias) gradient of the 3x3 convolution: Winograd-domain kernel wherever the geometry is served (VD_WINO=0 or
-    direct=True: the implicit GEMM over pixels)"""
+    """weight (and bias) gradient of the 3x3 convolution: Winograd-domain kernels wherever the geometry is served -- F(4x4,3x3)
+    unfused for the large layers, F(2x2,3x3) fused otherwise (VD_WINO=0 or direct=True: the implicit GEMM over pixels)"""
+    if not direct and wgrad43_supported(nimg, H, W, Cin, Cout, ldx, lddy):
+        return conv3x3_wgrad_wino43(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate, dbias)
     if WINO and not direct and lib().vd_conv3x3_wgrad_wino_supported(nimg, H, W, Cin, Cout, ldx, lddy):
         return conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_w, accumulate, dbias)
     nb = lib().vd_conv3x3_wgrad_ws_bytes(nimg, H, W, Cin, Cout)
