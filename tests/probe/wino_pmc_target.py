@@ -23,6 +23,7 @@ dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
 db = torch.empty(Cout, device=DEV)
 for _ in range(6):
     H.conv3x3_wino(x, Cin, uf, b, y, Cout, nimg, Hh, Ww, Cin, Cout, res=res, ldres=Cout, stats_part=part)
-    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
+    H.conv3x3_wgrad_wino(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)        # fused F(2x2,3x3) kernel (8x8 layers, small batches)
+    H.conv3x3_wgrad_wino43(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)      # what the step runs at this shape
     H.conv3x3_dgrad_wino43(dy, Cout, u43, dx, Cin, nimg, Hh, Ww, Cin, Cout)
 torch.cuda.synchronize()

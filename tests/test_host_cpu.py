@@ -410,3 +410,45 @@ def test_no_kernel_spills_to_scratch(tmp_path):
         bad = [k for k in ks if k["spill"] or k["scratch"]]
         assert not bad, f"{f}: kernels with spills / scratch: {bad[:4]}"
     assert total > 90
+
+
+def test_device_running_statistics_matches_reference_contract():
+    """DeviceRunningStatistics == reference RunningStatistics (train_utils.py:30-59) restated here: counts, sums of n * value,
+    extract() = sums / count, reset(), keys added on the fly; tensors and plain numbers are both accepted."""
+    import torch
+    from v_diffusion.trainer import DeviceRunningStatistics
+
+    class Ref:                                                     # the reference semantics, restated
+        def __init__(self, **kw):
+            self.count, self.stats = 0, {k: (v or 0) for k, v in kw.items()}
+        def reset(self):
+            self.count = 0
+            for k in self.stats:
+                self.stats[k] = 0
+        def update(self, n, **kw):
+            self.count += n
+            for k, v in kw.items():
+                self.stats[k] = self.stats.get(k, 0) + v
+        def extract(self):
+            return {k: v / self.count for k, v in self.stats.items()}
+
+    rng = np.random.default_rng(3)
+    ref, dev = Ref(loss=None), DeviceRunningStatistics(loss=None)
+    for step in range(50):
+        B = int(rng.integers(1, 129))
+        loss = float(rng.random())
+        ref.update(B, loss=loss * B)
+        dev.update(B, loss=torch.tensor(loss, dtype=torch.float32).double() * B if step % 2 else loss * B)
+        if step == 20:
+            ref.update(B, aux=1.5)
+            dev.update(B, aux=1.5)
+    assert dev.count == ref.count
+    got, want = dev.extract(), ref.extract()
+    assert got.keys() == want.keys()
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-7 * abs(want[k]), (k, got[k], want[k])
+    assert "Count(s): %d" % ref.count in repr(dev)
+    ref.reset(); dev.reset()
+    assert dev.count == 0 and all(v == 0 for v in dev.stats.values())
+    dev.update(2, loss=3.0)
+    assert dev.extract()["loss"] == 1.5

@@ -383,8 +383,10 @@ def test_hot_path_trainer_matches_torch_optimizer(vd):
     gen = torch.Generator(DEV).manual_seed(8191)            # the trainer's own stream (train_utils.py:124)
     x, _, _ = make_inputs(cfg, 4, case["R"], case["label"], seed=5)
     x = x.clamp(-1, 1).to(DEV)
+    losses = []
     for it in range(3):
         loss_fast = tr.step(x, None)
+        losses.append(float(loss_fast))
         t = torch.rand((4,), dtype=torch.float64, device=DEV, generator=gen)
         noise = torch.empty_like(x).normal_(generator=gen)
         loss = gd.train_loss(ref, x, t, None, noise).mean()
@@ -397,6 +399,8 @@ def test_hot_path_trainer_matches_torch_optimizer(vd):
         for k, p in ref.named_parameters():
             shadow[k] += (1 - decay) * (p.detach() - shadow[k])
         assert abs(float(loss_fast) - float(loss)) <= 1e-5 * max(abs(float(loss)), 1.0)
+    # the running statistics of train_utils.py:169, accumulated on the device (no per-step host sync)
+    assert tr.stats.count == 12 and abs(tr.current_stats["loss"] - sum(losses) / 3) <= 1e-6 * abs(sum(losses) / 3)
     ema = tr.flat.ema_state_dict()
     for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         # the key third of an attention block's proj_in.bias has an exactly-zero gradient (softmax is invariant to a constant added

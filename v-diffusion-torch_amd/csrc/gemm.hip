@@ -1033,13 +1033,15 @@ __global__ void pack_conv3x3_batched_kernel(const long long* items, int n) {
 }
 
 
-bool use_dma(const GemmArgs& a) {
-    static const bool legacy = getenv("VD_GEMM_LEGACY") != nullptr;       // A/B switch for profiling
-    if (legacy) return false;
-    // 32-bit byte offsets inside one block tile must stay below the descriptor range
+// operands inside the LDS-DMA kernel's range: 32-bit byte offsets inside one block tile must stay below the descriptor range
+bool dma_in_range(const GemmArgs& a) {
     const long long lim = 0x70000000LL / 4;
     return 128LL * a.lda + 128 < lim && 128LL * a.ldb + 128 < lim && 128LL * a.ldc + 128 < lim && 128LL * a.ldr + 128 < lim &&
            vd_aligned16(a.A) && vd_aligned16(a.B);
+}
+bool use_dma(const GemmArgs& a) {
+    static const bool legacy = getenv("VD_GEMM_LEGACY") != nullptr;       // forces the register-staged kernel (tests, A/B profiling)
+    return !legacy && dma_in_range(a);
 }
 
 // ---- block-tile menu.  Rectangular tiles exist for channel counts that are not multiples of 128 (CelebA: 192, 576, 960,
@@ -1280,7 +1282,8 @@ extern "C" int vd_gemm_grouped_wgrad(const float* const* A, const float* const* 
     a.A = A[0]; a.B = B[0];
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N; a.ldr = 0; a.nh = 1;
     a.alpha = 1.f; a.lgW = a.lgHW = -1; a.probe = 0;
-    VD_REQUIRE(use_dma(a), "vd_gemm_grouped_wgrad: operands outside the LDS-DMA kernel's range (alignment / row pitch)");
+    // (the grouped launch exists only on the LDS-DMA kernel: VD_GEMM_LEGACY does not apply to it)
+    VD_REQUIRE(dma_in_range(a), "vd_gemm_grouped_wgrad: operands outside the LDS-DMA kernel's range (alignment / row pitch)");
     const int tile = choose_tile(M, N, false, (long long)count * S, 0);
     const int tbm = TILES[tile].bm, tbn = TILES[tile].bn;
     const long long nm = (M + tbm - 1) / tbm, nn = (N + tbn - 1) / tbn;

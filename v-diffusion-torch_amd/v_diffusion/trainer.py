@@ -153,6 +153,59 @@ class GradReducer:
         self.works = []
 
 
+class DeviceRunningStatistics:
+    """Reference ``RunningStatistics`` (train_utils.py:30-59) with the sums kept on the device.
+
+    The reference closes every step with ``self.stats.update(B, loss=loss.item() * B)`` (train_utils.py:169): one host
+    synchronisation per step, which drains the launch queue (measured: 70.1 -> 72.0 ms per CIFAR step).  Here ``update``
+    takes the device scalar the step already has and adds ``n * value`` into a float64 device accumulator (the reference's
+    sums are Python floats: float64 too); the host reads the sums only in ``extract`` / ``repr`` -- once per progress-bar
+    refresh or epoch instead of once per step.  Plain numbers are accepted as well (the reference call style)."""
+
+    def __init__(self, device=None, **kwargs):
+        self.device = device
+        self.count = 0
+        self.keys = list(kwargs)
+        self.init = [float(v or 0) for v in kwargs.values()]
+        self._sums = None
+
+    def _buf(self):
+        if self._sums is None:
+            self._sums = torch.tensor(self.init, dtype=torch.float64, device=self.device)
+        return self._sums
+
+    def reset(self):
+        self.count = 0
+        self.init = [0.0] * len(self.keys)
+        if self._sums is not None:
+            self._sums.zero_()
+
+    def update(self, n, **kwargs):
+        """``n`` samples; every value is the batch SUM (``loss * B``) as a device scalar or a number (the reference's contract)"""
+        self.count += n
+        for k, v in kwargs.items():
+            if k not in self.keys:
+                self.keys.append(k)
+                self.init.append(0.0)
+                if self._sums is not None:
+                    self._sums = torch.cat([self._sums, self._sums.new_zeros(1)])
+            i = self.keys.index(k)
+            if torch.is_tensor(v):
+                self._buf()[i:i + 1].add_(v.detach().reshape(1).to(torch.float64))
+            else:
+                self._buf()[i] += float(v)
+
+    @property
+    def stats(self):
+        return dict(zip(self.keys, self._buf().tolist()))          # the one host synchronisation
+
+    def extract(self):
+        return {k: v / self.count for k, v in self.stats.items()}
+
+    def __repr__(self):
+        return "Count(s): {}\nStatistics:\n".format(self.count) + "".join(f"\t{k} = {v}\n" for k, v in self.stats.items())
+
+
 class HotPathTrainer:
     """Equivalent of reference ``Trainer.step`` for one rank (see module docstring)."""
 
@@ -167,6 +220,7 @@ class HotPathTrainer:
         self.reducer = GradReducer(self.flat, world_size, group=group)
         model._grads_ready_hook = None
         self.generator = torch.Generator(self.device).manual_seed(8191 + rank)       # train_utils.py:124
+        self.stats = DeviceRunningStatistics(device=self.device, loss=None)           # train_utils.py:135
         # the leader = first member of the process group (global rank 0 need not belong to a sub-group)
         self.leader = dist.get_global_rank(group, 0) if (world_size > 1 and group is not None) else 0
         self.is_leader = world_size == 1 or (dist.get_rank() == self.leader if dist.is_initialized() else rank == 0)
@@ -232,7 +286,12 @@ class HotPathTrainer:
         if self.world > 1:                                         # train_utils.py:156-158: the leader reports the rank mean
             dist.reduce(loss, dst=self.leader, op=dist.ReduceOp.SUM, group=self.reducer.group)
             loss.div_(self.world)
+        self.stats.update(x.shape[0], loss=loss * x.shape[0])      # train_utils.py:169, without its .item()
         return loss
+
+    @property
+    def current_stats(self):                                       # train_utils.py:305-307
+        return self.stats.extract()
 
     # ------------------------------------------------------------------ EMA weights for sampling (utils.py:151-166)
     def ema_weights(self):
