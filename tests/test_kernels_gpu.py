@@ -897,6 +897,9 @@ WINO43_CASES = [  # nimg, H, W, Cin, Cout, lddy_extra, lddx_extra
     (1, 16, 64, 32, 16, 0, 0),         # 64-wide image, one 16-row part
     (2, 64, 64, 64, 40, 0, 0),         # 64x64: 4 parts per image (interior parts have halo rows on both sides)
     (40, 32, 32, 256, 256, 0, 0),      # 40 x 8 = 320 items: one full persistent round (permuted ids) + a ragged one
+    (4, 16, 16, 32, 8, 0, 0),          # 16x16 images: four per item (shared zero rows between them), one item
+    (12, 16, 16, 96, 40, 8, 32),       # 3 image quads x 3 channel blocks, ld > C on both sides
+    (128, 16, 16, 256, 256, 0, 0),     # the CIFAR 16x16 level at batch 128: 32 quads x 8 channel blocks = one full round (4 x 8 item order)
 ]
 
 
@@ -931,7 +934,9 @@ def test_conv3x3_dgrad_wino43(H, case):
 
 def test_conv3x3_dgrad_wino43_rejects_unsupported(H):
     f = H.lib().vd_conv3x3_dgrad_wino43_supported
-    assert f(2, 16, 16, 32, 32, 32, 32) == 0             # 16x16 images (served by the F(2x2,3x3) kernels)
+    assert f(2, 16, 16, 32, 32, 32, 32) == 0             # 16x16 images are served four at a time
+    assert f(4, 16, 16, 32, 32, 32, 32) == 1
+    assert f(4, 8, 8, 32, 32, 32, 32) == 0               # 8x8 images (served by the F(2x2,3x3) kernels)
     assert f(2, 32, 32, 48, 32, 32, 48) == 0             # Cin % 32
     assert f(2, 32, 32, 32, 12, 12, 32) == 0             # Cout % 8
     assert f(2, 24, 64, 32, 32, 32, 32) == 0             # 64-wide, H % 16

@@ -47,7 +47,8 @@ struct Args43 {
     const float* U;                           // packed [N/32][K/8][36][4 kq][16 n][2 cb][2 j]
     float* y; long long ldy;                  // dx      [nimg][H][W][>= N]
     int nimg, H, W, K, N;
-    int items_per_img;                        // 1 (32x32) or H/16 (64 wide)
+    int items_per_img;                        // 1 (32x32) or H/16 (64 wide); 16x16 images: FOUR IMAGES per item (tile groups = nimg / 4)
+    int ngrp;                                 // tile groups (64 tiles each)
     int ncb, nitems;
 };
 
@@ -130,18 +131,26 @@ __device__ __forceinline__ void bt_full2(const f32x2 (&r)[6], f32x2 (&v)[6]) {
 #endif
 }
 
-// TWT = tiles per image row (8: 32-wide images, 16: 64-wide images)
+// TWT = tiles per image row (8: 32-wide images, 16: 64-wide images, 4: 16x16 images, four of them per item)
+// 16x16 images: the item's patch image stacks its four images vertically with ONE shared zero row between neighbours (rows 17 i are the
+// halo of image i-1 below and of image i above: 69 rows instead of 72), and the column classes keep only the slots that exist (x + 1 in
+// 0..17: classes 0, 1 have five slots, classes 2, 3 four) -- 19 slots per row, 42 KB per stage: the same footprint as a 32x32 image.
 template <int TWT>
 __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
-    constexpr int RUN = TWT + 1;                           // slots of one column class in a pixel row
-    constexpr int RP = 4 * RUN + ((TWT / 4) & 3);          // pixel-row pitch in slots: 4 * RP * 16 B == TWT * 16 B (mod 256 B)
-    constexpr int NTR = TILES / TWT;                       // tile rows per item (8 or 4)
-    constexpr int RIN = 4 * NTR + 2;                       // pixel rows held per item
+    constexpr bool QUAD = TWT == 4;
+    constexpr int RUN = TWT + 1;                           // slots of one column class in a pixel row (QUAD: of classes 0 and 1)
+    constexpr int RUNS = QUAD ? 4 * RUN - 2 : 4 * RUN;     // slots of a pixel row that hold pixels
+    // pixel-row pitch in slots: the tiles a wave reads together (16 / TWT tile rows of TWT tiles) must fall on different 16-byte bank
+    // groups: 4 * RP * 16 B == TWT * 16 B (mod 256 B)
+    constexpr int RP = QUAD ? RUNS + 1 : RUNS + ((TWT / 4) & 3);
+    constexpr int NTR = TILES / TWT;                       // tile rows per item (8 or 4; QUAD: 16 = 4 images x 4)
+    constexpr int RIN = QUAD ? 4 * 17 + 1 : 4 * NTR + 2;   // pixel rows held per item
     constexpr int NS = RIN * RP;                           // patch slots per granule
     constexpr int NPG = (NS + 63) / 64;                    // DMA pieces (1 KiB) per granule
     constexpr int A_STAGE = 2 * NPG * 256;                 // floats
     constexpr int STAGE = A_STAGE + U_STAGE;
-    constexpr int LGT = TWT == 8 ? 3 : 4;
+    constexpr int LGT = TWT == 4 ? 2 : TWT == 8 ? 3 : 4;
+    static_assert((4 * RP * 16) % 256 == (TWT * 16) % 256 || (QUAD && (4 * RP * 16) % 256 == 192), "row pitch leaves bank conflicts");
     static_assert(2 * STAGE * 4 <= 163840, "stages exceed the LDS");
     static_assert(8 * 16 * 64 * 16 <= 2 * STAGE * 4, "epilogue exchange area exceeds the stages");
     __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
@@ -156,8 +165,9 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
     // ---- DMA plan of this wave.  Patch pieces: granule wave & 1, slot groups (wave >> 1) + 4 j; U pieces wave + 8 j (linear copy).
     constexpr int APL = (NPG + 3) / 4;
     unsigned pxo[APL];
-    auto offsets = [&](int grp) {                                   // tile group = (image, part of the image)
-        const int img = grp / p.items_per_img;
+    const float* xitem = p.x;                                       // QUAD: first image of the item (the lane offsets pxo are item-invariant)
+    auto offsets = [&](int grp) {                                   // tile group = (image, part of the image) / QUAD: four images
+        int img = grp / p.items_per_img;
         const int part = grp - img * p.items_per_img;
         const int y_first = 4 * NTR * part - 1;
 #pragma unroll
@@ -165,11 +175,21 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             const int s = (wave >> 1) + 4 * j;
             const int slot = s * 64 + lane;
             const int r = slot / RP, cs = slot - r * RP;
-            const int c = cs / RUN, idx = cs - c * RUN;
-            const int xx = 4 * idx + c - 1, yy = y_first + r;
+            int c, idx, yy, im;
+            if (QUAD) {
+                c = cs >= 3 * RUN - 1 ? 3 : cs >= 2 * RUN ? 2 : cs >= RUN ? 1 : 0;
+                idx = cs - (c * RUN - (c == 3 ? 1 : 0));
+                const int i4 = r / 17;
+                im = i4; yy = r - 17 * i4 - 1;                      // row 17 i: the shared zero row (yy = -1); r = 68: i4 = 4 (no image)
+                if (i4 >= 4) yy = -1;                               // (offsets relative to the item's first image: xitem below)
+            } else {
+                c = cs / RUN; idx = cs - c * RUN;
+                im = img; yy = y_first + r;
+            }
+            const int xx = 4 * idx + c - 1;
             unsigned vo = OOB;
-            if (s < NPG && r < RIN && cs < 4 * RUN && (unsigned)xx < (unsigned)p.W && (unsigned)yy < (unsigned)p.H)
-                vo = (unsigned)(((img * p.H + yy) * p.W + xx) * (int)p.ldx) * 4u;
+            if (s < NPG && r < RIN && cs < RUNS && (unsigned)xx < (unsigned)p.W && (unsigned)yy < (unsigned)p.H)
+                vo = (unsigned)(((im * p.H + yy) * p.W + xx) * (int)p.ldx) * 4u;
             pxo[j] = vo;
         }
     };
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             const int j = i - 5;
             const int s = (wave >> 1) + 4 * j, g = wave & 1;
             if (s < NPG) {
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.x + kt * KT);
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(xitem + kt * KT);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sb + (g * NPG + s) * 256), 16, (int)pxo[j], g * 16, 0, 0);
             }
         }
@@ -201,14 +221,15 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
     // ---- LDS read addresses (floats): patch position (pr, q) of this lane's tile, channels {2 lq, 2 lq + 1}
     const int tl = 16 * tg + li;
     const int tyl = tl >> LGT, tx = tl & (TWT - 1);
-    const int pbase = ((lq >> 1) * NPG * 64 + 4 * tyl * RP + tx) * 4 + (lq & 1) * 2;
-    auto poff = [](int pr, int q) { return (pr * RP + (q & 3) * RUN + (q >> 2)) * 4; };
+    const int prow0 = QUAD ? 17 * (tyl >> 2) + 4 * (tyl & 3) : 4 * tyl;          // first patch row of this lane's tile
+    const int pbase = ((lq >> 1) * NPG * 64 + prow0 * RP + tx) * 4 + (lq & 1) * 2;
+    auto poff = [](int pr, int q) { return (pr * RP + ((q & 3) * RUN - (QUAD && (q & 3) == 3 ? 1 : 0)) + (q >> 2)) * 4; };
     const int uoff = A_STAGE + lane * 4;
 
     // item of round n: linear id n * G + w, re-ordered inside FULL rounds so that the workgroups of one XCD (w % 8) take 32
     // neighbouring ids, and 32 neighbouring ids are 4 channel blocks x 8 tile groups: the 4 blocks of a tile group share its patch
     // stream in that XCD's L2, the 8 tile groups of a block share its U stream (as in wino.hip)
-    const int ngrp = p.nimg * p.items_per_img;                      // tile groups (64 tiles each)
+    const int ngrp = p.ngrp;                                        // tile groups (64 tiles each)
     auto item_of = [&](int n, int& cb, int& grp) -> bool {
         int t = n * G + (int)blockIdx.x;
         if ((G & 7) == 0 && (n + 1) * G <= p.nitems) t = n * G + ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
@@ -241,8 +262,10 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             }
         };
         int cb = 0, grp = 0;
+        if (QUAD) offsets(0);
         for (int n = 0; item_of(n, cb, grp); ++n) {
-            offsets(grp);
+            if (QUAD) xitem = p.x + (long long)grp * (4 * 16 * 16) * p.ldx;
+            else offsets(grp);
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) issue_piece(i, 0, 0, cb);
             f32x4 acc[18][2];
@@ -358,10 +381,10 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             }
             {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const int img = grp / p.items_per_img;
-                const int part = grp - img * p.items_per_img;
+                const int img = QUAD ? 4 * grp + (tyl >> 2) : grp / p.items_per_img;
+                const int part = QUAD ? 0 : grp - img * p.items_per_img;
                 const int n0 = cb * TN + 16 * HALF + 4 * lq;
-                const int y0 = 4 * (NTR * part + tyl), x0 = 4 * tx;
+                const int y0 = QUAD ? 4 * (tyl & 3) : 4 * (NTR * part + tyl), x0 = 4 * tx;
                 const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
                 const unsigned ldy_u = (unsigned)p.ldy;
                 const unsigned pix00 = (unsigned)((img * p.H + y0) * p.W + x0);
@@ -593,11 +616,11 @@ thread_local int g_last43w = 0;        // split-K slabs of the calling thread's 
 
 }  // namespace
 
-/* 1 when vd_conv3x3_dgrad_wino43 serves the geometry: 32x32 images or 64-wide images with H % 16 == 0, Cout % 8 == 0 (GEMM K),
- * Cin % 32 == 0 (output channels), 16-byte aligned rows, tensors below 2 GiB */
+/* 1 when vd_conv3x3_dgrad_wino43 serves the geometry: 32x32 images, 64-wide images with H % 16 == 0, or 16x16 images in multiples of
+ * four; Cout % 8 == 0 (GEMM K), Cin % 32 == 0 (output channels), 16-byte aligned rows, tensors below 2 GiB */
 extern "C" int vd_conv3x3_dgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t lddy, int64_t lddx) {
     if (nimg <= 0 || Cout % KT || Cin % TN || lddy % 4 || lddx % 4) return 0;
-    if (!((W == 32 && H == 32) || (W == 64 && H % 16 == 0 && H >= 16))) return 0;
+    if (!((W == 32 && H == 32) || (W == 64 && H % 16 == 0 && H >= 16) || (W == 16 && H == 16 && nimg % 4 == 0))) return 0;
     const long long px = (long long)nimg * H * W, lim = 0x7FFFFFF0LL / 4;
     if (px * lddy >= lim || px * lddx >= lim) return 0;
     return 1;
@@ -616,22 +639,24 @@ extern "C" int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const floa
     Args43 a = {};
     a.x = dy; a.ldx = lddy; a.U = U43; a.y = dx; a.ldy = lddx;
     a.nimg = nimg; a.H = H; a.W = W; a.K = Cout; a.N = Cin;
-    a.items_per_img = W == 32 ? 1 : H / 16;
+    a.items_per_img = W == 64 ? H / 16 : 1;
+    a.ngrp = W == 16 ? nimg / 4 : nimg * a.items_per_img;
     a.ncb = Cin / TN;
-    const long long items = (long long)nimg * a.items_per_img * a.ncb;
+    const long long items = (long long)a.ngrp * a.ncb;
     VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_dgrad_wino43: too many work items");
     a.nitems = (int)items;
     const int ncu = vd_cu_count();
     const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(THREADS);
     hipStream_t st = (hipStream_t)stream;
-    if (W == 32) hipLaunchKernelGGL((wino43_dgrad_kernel<8>), grid, blk, 0, st, a);
+    if (W == 16) hipLaunchKernelGGL((wino43_dgrad_kernel<4>), grid, blk, 0, st, a);
+    else if (W == 32) hipLaunchKernelGGL((wino43_dgrad_kernel<8>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((wino43_dgrad_kernel<16>), grid, blk, 0, st, a);
     VD_LAUNCH_CHECK("wino43_dgrad_kernel");
-    g_last43 = W == 32 ? 8 : 16;
+    g_last43 = W / 4;
     return 0;
 }
 
-/* tiles per row (8 / 16) of the calling thread's last vd_conv3x3_dgrad_wino43 launch = the instantiation wino43_dgrad_kernel<TWT> */
+/* tiles per row (4 / 8 / 16) of the calling thread's last vd_conv3x3_dgrad_wino43 launch = the instantiation wino43_dgrad_kernel<TWT> */
 extern "C" int vd_wino43_last_kernel(void) { return g_last43; }
 
 extern "C" int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, void* stream) {

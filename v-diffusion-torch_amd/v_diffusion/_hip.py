@@ -312,11 +312,12 @@ def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres
 
 
 WINO43 = os.environ.get("VD_WINO43", "1") != "0"  # A/B switch: 0 keeps the input gradients on F(2x2,3x3)
+WINO43_MIN_W = int(os.environ.get("VD_WINO43_MIN_W", "16"))   # A/B switch: 32 keeps the 16x16 layers on F(2x2,3x3)
 
 
 def wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx):
     """input gradient of a Cin -> Cout convolution on (nimg, H, W) images through F(4x4,3x3)?"""
-    return WINO and WINO43 and bool(lib().vd_conv3x3_dgrad_wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx))
+    return WINO and WINO43 and W >= WINO43_MIN_W and bool(lib().vd_conv3x3_dgrad_wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx))
 
 
 def wino43_pack(w, Cout, Cin, U43):
