@@ -12,18 +12,19 @@ import _probe_lib  # noqa: F401,E402  (loads libvdiff_hip_probe.so: the product 
 from v_diffusion import _hip as H
 
 DEV = "cuda"
+# (the fused F(2x2,3x3) kernel itself: H.conv3x3_wgrad routes layers of this size to the unfused F(4x4,3x3) path since round 3)
 for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256), (128, 16, 16, 256, 256), (128, 8, 8, 256, 256)):
     x = torch.randn(nimg, Hh, Ww, Cin, device=DEV)
     dy = torch.randn(nimg, Hh, Ww, Cout, device=DEV)
     dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
     db = torch.empty(Cout, device=DEV)
     for _ in range(3):
-        H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
+        H.conv3x3_wgrad_wino(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
     buf = torch.zeros(4 * 4096, dtype=torch.int64, device=DEV)
     H.lib().vd_wino_set_probe(buf.data_ptr())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
+    H.conv3x3_wgrad_wino(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw, Cin, Cout, dbias=db)
     e1.record()
     torch.cuda.synchronize()
     H.lib().vd_wino_set_probe(None)
