@@ -136,8 +136,9 @@ int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or
  * gradients only (stated bound: per-tensor relative L2 <= 1e-4) and never the forward pass (autograd of modules.py:141-144).
  *   U43 = vd_wino43_pack(w): (G rot180(w[co][ci]) G^T)[36] in the order the kernel's lanes read it, vd_wino43_u_floats(Cout, Cin) floats;
  *   dx[nimg][H][W][:Cin] = vd_conv3x3_dgrad_wino43(dy[nimg][H][W][:Cout], U43)   every element written, no accumulation.
- * _supported: 1 for 32x32 images and 64-wide images with H % 16 == 0, Cout % 8 == 0, Cin % 32 == 0, 16-byte rows, tensors < 2 GiB;
- * otherwise call vd_conv3x3_wino with the rotated F(2x2,3x3) image.  vd_wino43_last_kernel: tiles per row (8 / 16) of the calling
+ * _supported: 1 for 32x32 images, 64-wide images with H % 16 == 0 and 16x16 images in multiples of four (four per work item),
+ * Cout % 8 == 0, Cin % 32 == 0, 16-byte rows, tensors < 2 GiB;
+ * otherwise call vd_conv3x3_wino with the rotated F(2x2,3x3) image.  vd_wino43_last_kernel: tiles per row (4 / 8 / 16) of the calling
  * thread's last launch = the instantiation wino43_dgrad_kernel<TWT> (profiling / test aid). */
 int vd_conv3x3_dgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t lddy, int64_t lddx);
 size_t vd_wino43_u_floats(int32_t Cout, int32_t Cin);

@@ -13,7 +13,7 @@
 //   M[xi][t][n]   = sum_k V[xi][t][k] U[xi][n][k]      36 independent GEMMs                                        (MFMA)
 //   dx[t][u][v][n] = (A^T M[.][t][n] A)[u][v]                                                                      (epilogue)
 //
-// Work item = 64 tiles (a 32x32 image, or 16 pixel rows of a 64-wide one) x 32 channels x all 36 xi; persistent workgroups of 8
+// Work item = 64 tiles (a 32x32 image, 16 pixel rows of a 64-wide one, or four 16x16 images) x 32 channels x all 36 xi; persistent workgroups of 8
 // waves (two per SIMD, <= 256 registers), one per CU (156-160 KB of LDS):
 //   * wave w owns tile group w & 3 (16 tiles) and HALF of xi: rows a in {3h .. 3h+2}, h = w >> 2, all six b -- 18 xi x 2 channel
 //     blocks = 144 accumulator registers.  Splitting xi by rows splits the input transform cleanly: the row pass of half h needs
