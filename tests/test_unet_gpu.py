@@ -147,6 +147,44 @@ def test_shard_gradients_sum_to_full_batch(vd):
         assert (f - p.grad).norm().item() <= 2e-5 * f.norm().item() + 1e-6 * gmax
 
 
+def test_side_stream_weight_gradients_are_bitwise_the_one_stream_result(vd):
+    """engine._cwgrad / _wgrad_flush: the weight gradients run on a side stream beside the rest of backward; every gradient tensor has
+    one writer, so the result must be bit-for-bit that of the one-stream order -- with and without a listener on the completion hook
+    (joins at every completion point / once at the end), and repeatedly (operands handed to the side stream are not recycled early)."""
+    from oracle.cases import CIFAR_COND, make_inputs
+    from oracle import detrand
+    from v_diffusion import _hip
+    cfg = dict(CIFAR_COND)
+    model, _ = _build(vd, cfg, train=True)
+    B = 8                                                   # 16x16 images in multiples of four: every F(4x4,3x3) path is taken
+    x, t, y = make_inputs(cfg, B, 32, "single", seed=9)
+    gout = detrand.normal("gout", (B, 3, 32, 32), 2).to(DEV)
+    x, t, y = x.to(DEV), t.to(DEV), y.to(DEV)
+
+    def grads(side, hook):
+        old = _hip.WGRAD_STREAM
+        _hip.WGRAD_STREAM = side
+        seen = []
+        model._grads_ready_hook = (lambda name: seen.append(name)) if hook else None
+        try:
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(5)                            # dropout seeds are drawn from the default generator
+            (model(x, t, y) * gout).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            _hip.WGRAD_STREAM = old
+            model._grads_ready_hook = None
+        return [p.grad.clone() for p in model.parameters()], seen
+    ref, _ = grads(False, False)
+    assert all(torch.isfinite(g).all() for g in ref)
+    for hook in (False, True):
+        for rep in range(2):
+            got, seen = grads(True, hook)
+            assert (len(seen) > 3) == hook
+            for (k, _), a, b in zip(model.named_parameters(), ref, got):
+                assert torch.equal(a, b), f"{k}: side-stream gradient differs (hook={hook}, repetition {rep})"
+
+
 def test_training_mode_dropout_runs_and_differs(vd):
     from oracle.cases import TINY, make_inputs
     case = TINY["tinyA"]

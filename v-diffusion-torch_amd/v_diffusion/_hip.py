@@ -359,6 +359,9 @@ def conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_
         _check(lib().vd_conv3x3_wgrad_wino_phase(*args, 2, stream()), "vd_conv3x3_wgrad_wino_phase")
 
 
+# weight gradients on a side stream beside the input-gradient / GroupNorm chain of backward (engine._cwgrad): -0.9 ms per CIFAR step,
+# -7 ms per CelebA step, same-box A/B; VD_WGRAD_STREAM=0 keeps everything on one stream
+WGRAD_STREAM = os.environ.get("VD_WGRAD_STREAM", "1") != "0"
 WINO43_WGRAD = os.environ.get("VD_WINO43_WGRAD", "1") != "0"   # A/B switch: 0 keeps every weight gradient on F(2x2,3x3)
 WINO43_WGRAD_MIN_TILES = int(os.environ.get("VD_WINO43_WGRAD_MIN_TILES", "2048"))   # (16x16 at batch 128: x1.2; below, the fused F(2x2,3x3) kernel is as fast)
 

@@ -137,6 +137,7 @@ class UNetEngine:
         self._norm_channels = sum(p.numel() for k, p in model.named_parameters()
                                   if k.endswith(".weight") and p.ndim == 1)          # all GroupNorm weights (the only 1-D weights)
         self._pgb_arena = self._pgb_table = None
+        self._side = self._side_stream = None     # side stream of the 3x3 weight gradients (VD_WGRAD_STREAM)
         self._wq = None                   # {shape key: [(dY, X, dW, dbias)]} of deferred weight-gradient GEMMs (inside backward only)
 
     # ------------------------------------------------------------------------------------------ small helpers
@@ -184,6 +185,27 @@ class UNetEngine:
         if len(q) == H.GROUP_MAX:
             self._wgrad_flush_key(key)
 
+    # ---- weight gradients on a side stream: nothing downstream in backward reads them, so they run beside the input-gradient /
+    # GroupNorm chain of the following blocks (an HBM-bound transform or GroupNorm pass next to an MFMA-bound GEMM or convolution instead
+    # of after it).  The side stream waits for the main stream before every launch (its operands are final), the operands are marked as
+    # used on it (the caching allocator must not hand their memory out while it still reads them), and the main stream waits for it
+    # wherever a gradient is declared complete: at every `progress` call when a reducer listens, else once at the end of backward.
+    # Results are bitwise those of the one-stream order (every gradient tensor has one writer); per-kernel profiling (H.PROFILE) runs
+    # on one stream so that a kernel's events bracket that kernel alone.
+    def _cwgrad(self, x, ldx, dy, lddy, *args, **kw):
+        side = self._side
+        if side is None:
+            return H.conv3x3_wgrad(x, ldx, dy, lddy, *args, **kw)
+        side.wait_stream(torch.cuda.current_stream())
+        x.record_stream(side)
+        dy.record_stream(side)
+        with torch.cuda.stream(side):
+            H.conv3x3_wgrad(x, ldx, dy, lddy, *args, **kw)
+
+    def _side_join(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def _wgrad_flush_key(self, key):
         q = self._wq.pop(key, None)
         if not q:
@@ -197,8 +219,21 @@ class UNetEngine:
         H.gemm_grouped_wgrad(q, M, N, K, lda, ldb, ldc, max(1, min(64, 1024 // max(tiles, 1), K // 256)))
 
     def _wgrad_flush(self):
-        for key in list(self._wq or {}):
-            self._wgrad_flush_key(key)
+        if not self._wq:
+            return
+        side = self._side
+        if side is None:
+            for key in list(self._wq):
+                self._wgrad_flush_key(key)
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        for q in self._wq.values():
+            for dy, x, _, _ in q:
+                dy.record_stream(side)
+                x.record_stream(side)
+        with torch.cuda.stream(side):
+            for key in list(self._wq):
+                self._wgrad_flush_key(key)
 
     # ---- GroupNorm parameter gradients: every norm's backward leaves its per-image dgamma / dbeta terms in a slice of one arena and
     # ONE launch at the end of backward sums them over the images for all norms (73 five-microsecond launches per CIFAR step before)
@@ -529,7 +564,7 @@ class UNetEngine:
         _, Ho, Wo, Cout, lddy = _chk(dy)
         rs = blk.rs
         # conv2
-        H.conv3x3_wgrad(a2, Cout, dy, lddy, B, Ho, Wo, Cout, Cout, G[prefix + ".conv2.weight"], Cout, Cout,
+        self._cwgrad(a2, Cout, dy, lddy, B, Ho, Wo, Cout, Cout, G[prefix + ".conv2.weight"], Cout, Cout,
                         dbias=G[prefix + ".conv2.bias"])
         da2 = self._new(x, B, Ho, Wo, Cout)
         self._conv(dy, lddy, mod.conv2.weight, None, da2, Cout, B, Ho, Wo, Cout, Cout, dgrad=True)
@@ -542,7 +577,7 @@ class UNetEngine:
                        pgb_keep=self._pgb(B, Cout, G[prefix + ".norm2.weight"], G[prefix + ".norm2.bias"]))
         del da2
         # conv1
-        H.conv3x3_wgrad(a1, Cin, dh1, Cout, B, Ho, Wo, Cin, Cout, G[prefix + ".conv1.weight"], Cin, Cout,
+        self._cwgrad(a1, Cin, dh1, Cout, B, Ho, Wo, Cin, Cout, G[prefix + ".conv1.weight"], Cin, Cout,
                         dbias=G[prefix + ".conv1.bias"])
         da1 = self._new(x, B, Ho, Wo, Cin)
         self._conv(dh1, Cout, mod.conv1.weight, None, da1, Cin, B, Ho, Wo, Cout, Cin, dgrad=True)
@@ -764,6 +799,7 @@ class UNetEngine:
         every entry overwritten) and returns d/dx (NCHW) when asked.  ``progress(name)`` is called whenever the gradient
         of ``name`` and of everything before it in trainer.completion_order() is final (gradient-bucket overlap)."""
         m = self.m
+        self._join_at_progress = progress is not None          # a gradient reducer is listening: finished means finished on every stream
         progress = progress or (lambda name: None)
         B, H0, W0, cop, _ = _chk(dout)
         ta = tape["ta"]
@@ -771,6 +807,11 @@ class UNetEngine:
         dfilms = {c2: self._new(ta, len(mods), B, c2) for c2, mods in self.film_groups.items()}
         self._pgb_begin(dout, B)
         self._wq = {}
+        self._side = None
+        if H.WGRAD_STREAM and H.PROFILE is None:
+            if self._side_stream is None or self._side_stream.device != dout.device:
+                self._side_stream = torch.cuda.Stream(device=dout.device)
+            self._side = self._side_stream
         # ---- out_conv
         C0 = m.hid_channels * m.ch_multipliers[0]
         gn, conv = m.out_conv[0], m.out_conv[2]
@@ -831,6 +872,8 @@ class UNetEngine:
             grp = lambda q: (q.level, "mid" if q.kind.startswith("mid") else q.kind)
             if nxt is None or grp(nxt) != grp(b):
                 self._wgrad_flush()
+                if self._join_at_progress:
+                    self._side_join()
                 progress(b.prefix + ".proj_in.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
             if b.kind == "up" and b.consumes:
                 dh_cur = dxbuf[..., :b.ch_h]
@@ -864,6 +907,8 @@ class UNetEngine:
         self._film_bwd(dfilms, tape["film_w"], dta)
         self._embed_bwd(tape["embed"], dta, G)
         self._wgrad_flush()
+        self._side_join()
+        self._side = None
         self._wq = None
         progress(None)
         return dx

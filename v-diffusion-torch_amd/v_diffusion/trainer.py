@@ -247,7 +247,7 @@ class HotPathTrainer:
             self._cls_grad = True                                  # some micro-batch of this update reached the class embedding
         loss = self.diffusion.train_loss(self.model, x_0=x, t=t, y=y, noise=noise).mean()
         self.reducer.start()
-        self.model._grads_ready_hook = self.reducer.ready
+        self.model._grads_ready_hook = self.reducer.ready if self.reducer.active else None     # (no listener: backward joins its side stream once, at the end)
         (loss / (self.num_accum * self.world)).backward()          # 1/world folds DDP's gradient averaging into the seed
         self.model._grads_ready_hook = None
         self.reducer.finish()
