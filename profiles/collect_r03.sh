@@ -7,6 +7,10 @@ cd "$(dirname "$0")/.."
 tail -3 $R/gputests.txt | head -2
 python profiles/parse_rocprof.py stats $R/prof_cifar/runc/*_kernel_stats.csv profiles/r03_train_step_kernel_stats.csv 9
 python profiles/parse_rocprof.py stats $R/prof_celeba/runc/*_kernel_stats.csv profiles/r03_celeba_train_step_kernel_stats.csv 6
+if [ -d $R/prof_cifar_1s ]; then
+python profiles/parse_rocprof.py stats $R/prof_cifar_1s/runc/*_kernel_stats.csv profiles/r03_train_step_kernel_stats_one_stream.csv 9
+python profiles/parse_rocprof.py stats $R/prof_celeba_1s/runc/*_kernel_stats.csv profiles/r03_celeba_train_step_kernel_stats_one_stream.csv 6
+fi
 python profiles/parse_rocprof.py traffic $R/pmc_fetch/runc/*_counter_collection.csv $R/pmc_write/runc/*_counter_collection.csv profiles/r03_traffic.json
 python profiles/parse_rocprof.py pmc profiles/r03_wino_pmc.json $R/pmc_wino/runc/*_counter_collection.csv $R/pmc_wino2/runc/*_counter_collection.csv
 python - $R <<'EOF'

@@ -22,6 +22,16 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_wino2 -- python3 $GRAFT_REPO_ROOT/tests/probe/wino_pmc_target.py > $OUT/pmc_wino2.log 2>&1
 cd $GRAFT_REPO_ROOT
 fi
+if [ "$WHAT" = all ] || [ "$WHAT" = prof1s ]; then
+# the same two workloads with the weight gradients on the main stream (VD_WGRAD_STREAM=0): every kernel runs alone, so the average
+# durations are the kernels' own (with the side stream a launch's duration includes the time it shares the chip with the other stream)
+cd /tmp && export TMPDIR=/tmp
+export VD_WGRAD_STREAM=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cifar_1s -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-sample --no-cpu-baseline --no-secondary --no-extras > $OUT/prof_cifar_1s.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_celeba_1s -- python3 $GRAFT_REPO_ROOT/bench.py --config celeba --steps 3 --warmup 1 --no-sample --no-cpu-baseline --no-secondary --no-extras > $OUT/prof_celeba_1s.log 2>&1
+unset VD_WGRAD_STREAM
+cd $GRAFT_REPO_ROOT
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = clock ]; then
 # in-kernel clock stamps (probe library): cycles per K tile and MHz of the Winograd forward / weight-gradient kernels
 VD_WINO_PROBE_LIGHT=1 timeout 600 python tests/probe/wino_phases.py > $OUT/wino_phases_light.txt 2>&1
