@@ -27,7 +27,8 @@ def timeit(fn, n=10):
 
 
 for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256), (128, 16, 16, 256, 256), (128, 16, 16, 512, 256),
-                                (128, 8, 8, 256, 256), (128, 64, 64, 192, 192), (128, 32, 32, 384, 384)):
+                                (128, 8, 8, 256, 256), (128, 64, 64, 192, 192), (128, 32, 32, 384, 384),
+                                (128, 8, 8, 768, 768), (128, 8, 8, 1536, 768), (128, 16, 16, 576, 576), (128, 16, 16, 1152, 576)):
     g = torch.Generator(DEV).manual_seed(1)
     x = F.silu(torch.randn((nimg, Hh, Ww, Cin), device=DEV, generator=g))
     dy = torch.randn((nimg, Hh, Ww, Cout), device=DEV, generator=g) * 0.05

@@ -979,7 +979,8 @@ def test_gemm_grouped_wgrad(H, count, M, N, K, splitk, pad):
 
 # ------------------------------------------------------------------------------------------------ F(4x4,3x3) weight gradient (unfused)
 WGRAD43_CASES = [  # nimg, H, W, Cin, Cout, Cin_w, Cout_w, ldx_extra, lddy_extra
-    (16, 32, 32, 32, 64, 32, 64, 0, 0),        # 1024 tiles: the smallest served problem
+    (16, 32, 32, 32, 64, 32, 64, 0, 0),        # 1024 tiles
+    (128, 8, 8, 64, 96, 64, 96, 0, 0),         # 512 tiles: the smallest served problem (8x8 images at batch 128)
     (9, 64, 32, 48, 36, 48, 36, 16, 12),       # non-square, channel counts off the tile sizes, ld > C on both sides
     (64, 16, 16, 96, 32, 96, 32, 0, 0),        # 16x16 images
     (20, 32, 32, 4, 32, 3, 32, 0, 0), (20, 32, 32, 32, 4, 32, 3, 0, 0),      # padded thin sides

@@ -676,11 +676,11 @@ extern "C" int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64
 }
 
 /* ---- weight (and bias) gradient of the 3x3 convolution through F(4x4,3x3), unfused: same arguments and result as vd_conv3x3_wgrad_wino.
- * Serves H, W multiples of 4 and Cin, Cout multiples of 4; _supported additionally requires at least 1024 tiles (below that the
- * F(2x2,3x3) kernel is faster) and tensors below 2 GiB. */
+ * Serves H, W multiples of 4 and Cin, Cout multiples of 4; _supported additionally requires at least 512 tiles (the K of the 36 GEMMs:
+ * 8x8 images at batch 128; below that the fused F(2x2,3x3) kernel is faster) and tensors below 2 GiB. */
 extern "C" int vd_conv3x3_wgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t lddy) {
     const Wg43Plan g = wg43_plan(nimg, H, W, Cin, Cout);
-    if (!g.ok || ldx % 4 || lddy % 4 || g.T < 1024 || g.T % 4) return 0;
+    if (!g.ok || ldx % 4 || lddy % 4 || g.T < 512 || g.T % 4) return 0;
     const long long px = (long long)nimg * H * W, lim = 0x7FFFFFF0LL / 4;
     if (px * ldx >= lim || px * lddy >= lim) return 0;
     if ((long long)g.T * (Cin > Cout ? Cin : Cout) * 4 >= (1LL << 40)) return 0;

@@ -363,7 +363,9 @@ def conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_
 # -7 ms per CelebA step, same-box A/B; VD_WGRAD_STREAM=0 keeps everything on one stream
 WGRAD_STREAM = os.environ.get("VD_WGRAD_STREAM", "1") != "0"
 WINO43_WGRAD = os.environ.get("VD_WINO43_WGRAD", "1") != "0"   # A/B switch: 0 keeps every weight gradient on F(2x2,3x3)
-WINO43_WGRAD_MIN_TILES = int(os.environ.get("VD_WINO43_WGRAD_MIN_TILES", "2048"))   # (16x16 at batch 128: x1.2; below, the fused F(2x2,3x3) kernel is as fast)
+# fewest 4x4-output tiles (= K of the 36 GEMMs) it is picked for: 512 = 8x8 images at batch 128 (256 -> 256: x1.17, 768 -> 768: x1.41 over the fused
+# F(2x2,3x3) kernel, same-box A/B tests/perf_wgrad43.py); the library serves nothing below 512
+WINO43_WGRAD_MIN_TILES = int(os.environ.get("VD_WINO43_WGRAD_MIN_TILES", "512"))
 
 
 def wgrad43_supported(nimg, H, W, Cin, Cout, ldx, lddy):
