@@ -362,6 +362,9 @@ def conv3x3_wgrad_wino(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cout_
 # weight gradients on a side stream beside the input-gradient / GroupNorm chain of backward (engine._cwgrad): -0.9 ms per CIFAR step,
 # -7 ms per CelebA step, same-box A/B; VD_WGRAD_STREAM=0 keeps everything on one stream
 WGRAD_STREAM = os.environ.get("VD_WGRAD_STREAM", "1") != "0"
+# slab count of the grouped 1x1 / linear weight gradients from vd_gemm_grouped_wgrad_auto_split (whole residency rounds: -0.5 ms per CIFAR
+# step against the fixed 1024-workgroup rule, same-box A/B); VD_GROUPED_AUTO_SPLIT=0: that rule
+GROUPED_AUTO_SPLIT = os.environ.get("VD_GROUPED_AUTO_SPLIT", "1") != "0"
 WINO43_WGRAD = os.environ.get("VD_WINO43_WGRAD", "1") != "0"   # A/B switch: 0 keeps every weight gradient on F(2x2,3x3)
 # fewest 4x4-output tiles (= K of the 36 GEMMs) it is picked for: 512 = 8x8 images at batch 128 (256 -> 256: x1.17, 768 -> 768: x1.41 over the fused
 # F(2x2,3x3) kernel, same-box A/B tests/perf_wgrad43.py); the library serves nothing below 512

@@ -215,8 +215,12 @@ class UNetEngine:
             for dy, x, dw, db in q:
                 H.gemm(dy, x, dw, M, N, K, a_kind=H.COL, b_kind=H.COL, lda=lda, ldb=ldb, ldc=ldc, splitk=_splitk(M, N, K), colsum=db)
             return
-        tiles = ((M + 63) // 64) * ((N + 63) // 64) * len(q)
-        H.gemm_grouped_wgrad(q, M, N, K, lda, ldb, ldc, max(1, min(64, 1024 // max(tiles, 1), K // 256)))
+        if H.GROUPED_AUTO_SPLIT:      # slab count that fills whole residency rounds of the chip (vd_gemm_grouped_wgrad_auto_split)
+            S = H.lib().vd_gemm_grouped_wgrad_auto_split(len(q), M, N, K, 1, 64)
+        else:
+            tiles = ((M + 63) // 64) * ((N + 63) // 64) * len(q)
+            S = max(1, min(64, 1024 // max(tiles, 1), K // 256))
+        H.gemm_grouped_wgrad(q, M, N, K, lda, ldb, ldc, S)
 
     def _wgrad_flush(self):
         if not self._wq:
