@@ -9,7 +9,7 @@ L=$ROOT/v-diffusion-torch_amd/lib/exp
 if [ "$1" = build ]; then
   mkdir -p $L
   for e in ${W43_EXPS:-0 1 2 3 4 5}; do
-    /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function -DVD_W43_EXP=$e $W43_EXTRA -c $C/wino43.hip -o /tmp/w43_$e.o
+    /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function -DVD_W43_EXP=$e -DVD_W43_SCRATCH_BUILD $W43_EXTRA -c $C/wino43.hip -o /tmp/w43_$e.o
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $L/libw43_$e.so $C/gemm.o $C/wino.o /tmp/w43_$e.o $C/attn.o $C/norm.o $C/misc.o $C/diffusion.o $C/optim.o $C/api.o
   done
 else

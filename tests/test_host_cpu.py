@@ -94,6 +94,26 @@ def test_state_dict_contract_cpu(golden_dir, cfgname):
         assert [str(n) for n in g["grad_names"]] == [k for k, _ in m.named_parameters()]      # reference parameters() order
 
 
+def test_use_xformers_flag_falls_back_to_the_plain_attention_block(capsys):
+    """SURVEY 8a row 17 (reference unet.py:192-199): without the xformers package the reference prints a message, resets the flag and
+    builds the plain AttentionBlock -- conv-shaped `proj_in` / `proj_out` parameters, none of XFormersAttentionBlock's
+    `to_q` / `to_k` / `to_v` linears (unet.py:84-103).  Same parameter set, same state_dict as use_xformers=False."""
+    from oracle import cases
+    import v_diffusion
+    cfg = cases.TINY["tinyA"]["cfg"]
+    ref = v_diffusion.UNet(**cfg)
+    capsys.readouterr()
+    m = v_diffusion.UNet(**cfg, use_xformers=True)
+    assert "xFormers not available! Resetting to False." in capsys.readouterr().out
+    keys = list(m.state_dict().keys())
+    assert keys == list(ref.state_dict().keys())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in ref.state_dict().values()]
+    assert any(k.endswith("proj_in.weight") for k in keys) and any(k.endswith("proj_out.weight") for k in keys)
+    assert not any(("to_q" in k) or ("to_k" in k) or ("to_v" in k) for k in keys)
+    pin = next(v for k, v in m.state_dict().items() if k.endswith("proj_in.weight"))
+    assert pin.ndim == 4 and pin.shape[2:] == (1, 1)                       # a 1x1 convolution, not a Linear
+
+
 def test_engine_plan_concat_wiring():
     from oracle import cases
     import v_diffusion

@@ -66,6 +66,40 @@ def test_two_rank_launch_contract_on_one_gpu():
     assert 0.0 < j["config"]["final_loss"] < 10.0
 
 
+def test_two_ranks_equal_one_rank_on_the_full_batch(tmp_path):
+    """End-to-end data-parallel equivalence (reference DDP semantics, train.py:141-148 + train_utils.py:151-169): two ranks, each with
+    half of a fixed batch (rows [r B/2, (r+1) B/2), injected t / noise), run two HotPathTrainer.step updates -- bucketed gradient
+    all-reduce launched from inside backward, 1 / world folded into the loss seed, clip + AdamW + EMA on the reduced gradient, loss
+    reduce to the leader -- and must land on the parameters / EMA shadow of ONE rank stepping on the full batch, and report the same
+    loss (the rank mean of shard means = the batch mean).  The ranks share the test box's one GPU; collectives over gloo.
+    Tolerances: the all-reduced gradient differs from the one-rank gradient only by fp32 summation order (relative L2 <= 1e-6 of the
+    buffer); parameters after two Adam steps at lr = 2e-4 without warm-up: relative L2 <= 1e-6 (Adam's first steps are sign-like, so a
+    handful of near-zero gradient entries may flip: measured and bounded on the whole buffer, not per element)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import dp_worker
+    out = str(tmp_path / "dp2.pt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29553", os.path.join(ROOT, "tests", "dp_worker.py"), "--out", out, "--batch", "16", "--steps", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    two = torch.load(out)
+    one = dp_worker.run(0, 1, 16, 2)
+    assert two["reducer_active"] and not one["reducer_active"] and two["buckets"] == 8
+    assert two["replicas_identical"], "the two replicas diverged"
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    eg, ep, ee = rel(two["g1"] * 1.0, one["g1"]), rel(two["p"], one["p"]), rel(two["ema"], one["ema"])
+    print(f"2 ranks x 8 rows vs 1 rank x 16 rows: gradient rel-L2 {eg:.2e}, parameters {ep:.2e}, EMA {ee:.2e}; losses {two['losses']} vs {one['losses']}")
+    assert eg <= 1e-6 and ep <= 1e-6 and ee <= 1e-6
+    # and the update itself: each element moved by ~lr per step, 1e-2 of a typical weight -- the displacement must agree too
+    ed = rel(two["p"].double() - two["p0"].double(), one["p"].double() - one["p0"].double())
+    assert torch.equal(two["p0"], one["p0"]) and ed <= 1e-3, f"displacement rel-L2 {ed:.2e}"
+    for a, b in zip(two["losses"], one["losses"]):
+        assert abs(a - b) <= 2e-6 * max(abs(b), 1.0), (two["losses"], one["losses"])
+
+
 def test_two_rank_rccl_launch_when_two_gpus_are_visible():
     """The same launch line over RCCL, one rank per GPU -- runs wherever the box has at least two devices (the build's own boxes
     have one: skipped there; the driver's multi-GPU node exercises it without further work).  Checks the contract line AND the

@@ -70,6 +70,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #ifndef VD_W43_EXP
 #define VD_W43_EXP 0
 #endif
+#if VD_W43_EXP != 0 && !defined(VD_W43_SCRATCH_BUILD)
+#error "VD_W43_EXP builds compute wrong results: only tests/probe/w43_exp.sh may build them (into scratch libraries, -DVD_W43_SCRATCH_BUILD)"
+#endif
 #ifndef VD_W43_SB
 #define VD_W43_SB 12          /* MFMA step (of 18 per K tile) the tile barrier sits in front of */
 #endif
@@ -255,7 +258,10 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
                 for (int pr = 0; pr < 6; ++pr) {
                     if ((HALF == 0 && pr == 5) || (HALF == 1 && pr == 0)) d[pr] = f32x2{0.f, 0.f};
                     else if (VD_W43_EXP >= 3 && VD_W43_EXP <= 4) d[pr] = f32x2{(float)pr, (float)q};
-                    else d[pr] = *reinterpret_cast<const f32x2*>(sa + poff(pr, q));
+                    // (volatile: keeps each read a ds_read_b64 -- banks (a/4) mod 64, 32-lane groups, conflict-free on this image.  Left to
+                    //  itself hipcc pairs them into ds_read2_b64, which is served in 16-lane groups on 32 banks at half the rate: the two
+                    //  tile rows of a wave then collide 2-way.  PMC round 3: SQ_LDS_BANK_CONFLICT 2.7e7 per launch, 0 in every other kernel)
+                    else d[pr] = *(const volatile __attribute__((address_space(3))) f32x2*)((const __attribute__((address_space(3))) float*)sa + poff(pr, q));
                 }
                 if (VD_W43_EXP >= 2 && VD_W43_EXP <= 4) { Rn[0][q] = d[1]; Rn[1][q] = d[2]; Rn[2][q] = d[3]; }
                 else bt_half2<HALF>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
@@ -497,7 +503,7 @@ struct WgT43 {
 
 // block (64 channel quads, 4 tiles); grid (ceil(max(Cin, Cout) / 256), T / 4, 2): z = 0 transforms the input patches, z = 1 the gradients
 __global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43 p) {
-    const int quad = blockIdx.x * 64 + threadIdx.x, tile = blockIdx.y * 4 + threadIdx.y;
+    const int quad = blockIdx.y * 64 + threadIdx.x, tile = blockIdx.x * 4 + threadIdx.y;      // (tiles on grid.x: no 65 535 bound)
     if (tile >= p.T) return;
     const int img = tile / p.TPI, tin = tile - img * p.TPI;
     const int ty = tin / p.TW, tx = tin - ty * p.TW;
@@ -715,7 +721,7 @@ static int wgrad43_impl(const float* xin, int64_t ldx, const float* dy, int64_t 
         t.x = xin; t.ldx = ldx; t.dy = dy; t.lddy = lddy; t.V = V; t.dM = dM;
         t.nimg = nimg; t.H = H; t.W = W; t.Cin = Cin; t.Cout = Cout; t.TW = W / 4; t.TPI = (H / 4) * (W / 4); t.T = g.T;
         const int cmax = Cin > Cout ? Cin : Cout;
-        hipLaunchKernelGGL(wino43_wgrad_transform_kernel, dim3((unsigned)((cmax + 255) / 256), (unsigned)(g.T / 4), 2), dim3(64, 4), 0, st, t);
+        hipLaunchKernelGGL(wino43_wgrad_transform_kernel, dim3((unsigned)(g.T / 4), (unsigned)((cmax + 255) / 256), 2), dim3(64, 4), 0, st, t);
         VD_LAUNCH_CHECK("wino43_wgrad_transform_kernel");
     }
     if (phases & 2) {

@@ -10,9 +10,11 @@ Data layout in HBM
     ``[0,Ch)`` and the producer of the skip tensor (a down-block, run much earlier) writes ``[Ch,Ch+Cs)``
     directly from their conv epilogues; gradients flow back the same way (the down-block's input gradient is
     accumulated into the skip slice of the up-block's input gradient).
-  * weights stay in the reference's OIHW / (out,in) storage; 3x3 kernels are re-packed to [Cout][tap][Cin]
-    (forward) and [Cin][tap'][Cout] (input gradient) per call -- 0.3 ms per UNet pass, always coherent with
-    whatever mutated the parameters (optimizer, load_state_dict, EMA swap through ``.data``).
+  * weights stay in the reference's OIHW / (out,in) storage; the 3x3 kernels of the residual blocks are transformed per call
+    into the Winograd domain by ONE launch for the whole network -- U = G w G^T as [16][Cout][Cin] (forward), [16][Cin][Cout]
+    (F(2x2,3x3) input gradient) or the 36-plane lane-ordered image of csrc/wino43.hip (F(4x4,3x3) input gradient): 0.2 ms per
+    train step, always coherent with whatever mutated the parameters (optimizer, load_state_dict, EMA swap through ``.data``).
+    The direct [Cout][tap][Cin] / [Cin][tap'][Cout] packs exist only for geometries the Winograd kernels decline.
   * the tape (what backward needs) is a python list of per-block dicts of buffers; with 288 GB of HBM nothing is
     recomputed except the dropout mask (counter-based Philox, regenerated from (seed, element index)).
 """
@@ -211,7 +213,11 @@ class UNetEngine:
         if not q:
             return
         M, N, K, lda, ldb, ldc, _ = key
-        if len(q) == 1 or M % 4 or N % 4:
+        # the grouped launch exists on the LDS-DMA tile engine only: every entry needs what that kernel needs (16-byte aligned operands,
+        # pitches that are multiples of 4 floats and inside its 32-bit offset range); anything else takes the per-entry launches
+        ok = M % 4 == 0 and N % 4 == 0 and lda % 4 == 0 and ldb % 4 == 0 and max(lda, ldb, ldc) * 128 + 128 < 0x70000000 // 4 and \
+            all(dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 for dy, x, _, _ in q)
+        if len(q) == 1 or not ok:
             for dy, x, dw, db in q:
                 H.gemm(dy, x, dw, M, N, K, a_kind=H.COL, b_kind=H.COL, lda=lda, ldb=ldb, ldc=ldc, splitk=_splitk(M, N, K), colsum=db)
             return
@@ -366,13 +372,20 @@ class UNetEngine:
         """3x3 convolution with kernel ``w`` (forward) or its input gradient (``dgrad``: x = dy, Cin/Cout are the GEMM's):
         Winograd F(2x2,3x3) wherever the geometry is served, the direct implicit GEMM otherwise."""
         wino = getattr(self, "_wino", None)
-        if wino is not None and dgrad and id(w) in wino and wino[id(w)][2] is not None:
-            # F(4x4,3x3) input gradient (csrc/wino43.hip): x = dy [.., Cin = conv Cout], y = dx [.., Cout = conv Cin]
+        if wino is not None and dgrad and id(w) in wino and wino[id(w)][2] is not None \
+                and H.wino43_supported(B, Hh, Ww, Cout, Cin, ldx, ldy):
+            # F(4x4,3x3) input gradient (csrc/wino43.hip): x = dy [.., Cin = conv Cout], y = dx [.., Cout = conv Cin].  The pack-time choice
+            # (_pack_all) saw dense pitches; the check above is the one with the pitches of THIS call (dy may be a channel slice of a concat
+            # buffer) and of this geometry -- a layer it declines falls through to the F(2x2,3x3) / direct forms below.
             assert res is None and bias is None and stats_part is None
             H.conv3x3_dgrad_wino43(x, ldx, wino[id(w)][2], y, ldy, B, Hh, Ww, Cout, Cin)
             return
         if wino is not None and id(w) in wino and H.wino_supported(B, Hh, Ww, Cin, Cout, ldx, ldy, ldres if res is not None else 0):
             U = wino[id(w)][1 if dgrad else 0]
+            if U is None and dgrad:
+                # a layer packed for the F(4x4,3x3) input gradient whose call declined it: rotated F(2x2,3x3) image on demand
+                U = torch.empty(16, w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
+                H.wino_pack(w, w.shape[0], w.shape[1], ud=U)
             if U is not None:
                 H.conv3x3_wino(x, ldx, U, bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres, stats_part=stats_part)
                 return
@@ -793,12 +806,21 @@ class UNetEngine:
             tape["ta"] = ta
             tape["in"] = dict(x4=x4 if xc is None else None, xc=xc, cip=cip)
             tape["out"] = dict(h=h, coef=coef, a=a, wz=wz)
+            tape["wino"] = getattr(self, "_wino", None)
         return out, tape
 
     def new_grads(self):
         return {k: torch.empty_like(p) for k, p in self.m.named_parameters()}
 
     def backward(self, tape, dout, G, need_dx=False, progress=None):
+        """see _backward; the deferred weight-gradient queue and the side stream never outlive the call, whatever it raises"""
+        try:
+            return self._backward(tape, dout, G, need_dx, progress)
+        finally:
+            self._wq = None
+            self._side = None
+
+    def _backward(self, tape, dout, G, need_dx=False, progress=None):
         """dout: NHWC ``[B,H,W,Cp]`` gradient of the padded output (padding channels zero).  Fills ``G`` (name -> tensor,
         every entry overwritten) and returns d/dx (NCHW) when asked.  ``progress(name)`` is called whenever the gradient
         of ``name`` and of everything before it in trainer.completion_order() is final (gradient-bucket overlap)."""
@@ -806,6 +828,7 @@ class UNetEngine:
         self._join_at_progress = progress is not None          # a gradient reducer is listening: finished means finished on every stream
         progress = progress or (lambda name: None)
         B, H0, W0, cop, _ = _chk(dout)
+        self._wino = tape.get("wino", getattr(self, "_wino", None))     # the Winograd images THIS forward packed (another forward may have run since)
         ta = tape["ta"]
         dta = torch.zeros_like(ta)
         dfilms = {c2: self._new(ta, len(mods), B, c2) for c2, mods in self.film_groups.items()}

@@ -224,10 +224,17 @@ class HotPathTrainer:
         # the leader = first member of the process group (global rank 0 need not belong to a sub-group)
         self.leader = dist.get_global_rank(group, 0) if (world_size > 1 and group is not None) else 0
         self.is_leader = world_size == 1 or (dist.get_rank() == self.leader if dist.is_initialized() else rank == 0)
+        self._flag_group = None
         if world_size > 1:                                                            # DDP ctor broadcast (train.py:148)
             dist.broadcast(self.flat.p, src=self.leader, group=group)
             if self.flat.ema is not None:
                 self.flat.ema.copy_(self.flat.p)
+            if self.flat.cls_range is not None:
+                # whether the class embedding received a gradient in an update must be ONE decision for all replicas (the gradients are
+                # averaged over ranks; a rank-local decision would let replicas that saw y = None skip an update the others apply).  The
+                # flag travels as a host integer over a gloo group: no device synchronisation on the step's critical path.
+                ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+                self._flag_group = dist.new_group(ranks=ranks, backend="gloo")
 
     def draw(self, x):
         B = x.shape[0]
@@ -239,10 +246,12 @@ class HotPathTrainer:
         noise = torch.empty_like(x).normal_(generator=self.generator)
         return t, noise
 
-    def step(self, x, y, update=True):
-        """One micro-batch: returns the detached mean loss (device tensor; no host sync here)."""
+    def step(self, x, y, update=True, t=None, noise=None):
+        """One micro-batch: returns the detached mean loss (device tensor; no host sync here).  ``t`` / ``noise`` replace the draw from
+        the per-rank generator (tests: the same rows through one rank and through two must give the same update)."""
         flat = self.flat
-        t, noise = self.draw(x)
+        if t is None or noise is None:
+            t, noise = self.draw(x)
         if y is not None:
             self._cls_grad = True                                  # some micro-batch of this update reached the class embedding
         loss = self.diffusion.train_loss(self.model, x_0=x, t=t, y=y, noise=noise).mean()
@@ -271,7 +280,12 @@ class HotPathTrainer:
             if flat.cls_range is not None:
                 # reference semantics of parameters without a gradient (torch.optim.AdamW skips them: no moment decay, no weight
                 # decay, no update, their own step counter): see vd_adamw_ema
-                if not getattr(self, "_cls_grad", False):
+                cls_grad = bool(getattr(self, "_cls_grad", False))
+                if self._flag_group is not None:                   # any rank had labels -> every rank applies the averaged gradient
+                    f = torch.tensor([int(cls_grad)], dtype=torch.int32)
+                    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self._flag_group)
+                    cls_grad = bool(f.item())
+                if not cls_grad:
                     rng = dict(r_lo=flat.cls_range[0], r_hi=flat.cls_range[1], r_mode=1)
                 else:
                     flat.cls_steps += 1
