@@ -131,9 +131,13 @@ WORKLOADS = {
 PEAK_HBM_TBS = 8.0                     # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured for a streaming copy)
 
 
-def traffic_table():
-    """HBM bytes per launch from the committed PMC passes (profiles/parse_rocprof.py): newest round first"""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+def traffic_table(wl="cifar10"):
+    """HBM bytes per launch from the committed PMC passes of THIS workload (profiles/parse_rocprof.py; separate --pmc passes cannot run
+    inside the timed bench, so the figure is a tracked measurement of the same command and says which file it came from): newest round
+    first; a workload without a PMC pass of its own gets no table (its `traffic` is null, never another workload's number)"""
+    names = {"cifar10": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"),
+             "celeba": ("r04_celeba_traffic.json",)}[wl]
+    for name in names:
         try:
             return name, json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         except Exception:
@@ -168,16 +172,35 @@ def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, ba
         tmax = torch.tensor([ds], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ds = float(tmax.item())
+    # share of the algorithmic FLOPs the matrix cores execute in THIS sampler, from the launches two reverse steps record (each launch
+    # carries the 2*M*N*K of the op it implements; executed_share() says what its kernel really multiplies)
+    exec_frac, rec_gflop = W["fwd_exec_frac"], None
+    if rank == 0:
+        from v_diffusion import _hip
+        xt = torch.randn((SB, 3, RES, RES), device=device)
+        _hip.PROFILE = []
+        with torch.inference_mode():
+            for st in (T - 1, T // 2):
+                xt = diffusion.p_sample_step(model, xt, torch.full((SB,), st, device=device), lab.clone(), use_ddim=True)
+        torch.cuda.synchronize()
+        rec, _hip.PROFILE = _hip.PROFILE, None
+        fl = sum(r[1] for r in rec if not r[0].startswith("hbm:"))
+        fe = sum(r[1] * executed_share(r[0]) for r in rec if not r[0].startswith("hbm:"))
+        if fl > 0:
+            exec_frac, rec_gflop = fe / fl, fl / 2 / (2 * SB) / 1e9      # recorded algorithmic GFLOP per UNet row (fwd_gflop)
     model.train()
     alg = T * 2 * W["fwd_gflop"] * SB / ds / 1e3                      # algorithmic TFLOP/s (2 x T x forward)
-    exe = alg * W["fwd_exec_frac"]
+    exe = alg * exec_frac
     return {"metric": f"ddim{T}_cfg_samples_per_sec", "value": round(world * SB / ds, 2), "unit": "images/s",
             "seconds_per_batch": round(ds, 3), "batch_per_gpu": SB, "unet_rows_per_step": 2 * SB, "w_guide": float(diffusion.w_guide),
             "roofline": {"bound": "mfma", "achieved": round(exe, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(exe / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic_tflops": round(alg, 2),
                          "speedup_vs_direct_roofline": round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "note": "achieved = MFMA FLOPs executed (Winograd convolutions count 4/9 of their algorithmic FLOPs); "
-                                 "algorithmic_tflops = SURVEY 8d count of the direct convolution"},
+                         "frac_vs_direct_roofline": round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "executed_share_of_algorithmic_flops": round(exec_frac, 4),
+                         "recorded_gflop_per_unet_row": None if rec_gflop is None else round(rec_gflop, 2),
+                         "note": "achieved = MFMA FLOPs executed: the share comes from the launches two reverse steps of this run record "
+                                 "(Winograd convolutions execute 4/9 of their algorithmic FLOPs); algorithmic_tflops = SURVEY 8d count"},
             "finite": bool(torch.isfinite(out).all())}
 
 
@@ -200,7 +223,9 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+            hp = os.environ.get("VD_RCCL_HIGH_PRIORITY", "0") != "0"
+            dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0,
+                                    pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True) if hp else None)
         trainer.reducer.active = True
     RES = W["res"]
     g = torch.Generator(device).manual_seed(4321 + rank)
@@ -254,6 +279,7 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
     # ---- live roofline: HIP events around every matmul-shaped and GroupNorm launch of two extra steps
     if rank == 0:
         _hip.PROFILE = []
+        _hip.PROFILE_BYTES.clear()
     for _ in range(2):                  # every rank takes part (the steps contain collectives); only rank 0 records
         one_step()
     barrier()
@@ -268,9 +294,11 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
         total_t = sum(v[1] for v in agg.values())
         dom = max(agg, key=lambda k: agg[k][1])
         fl, tt_, n = agg[dom]
-        tname, tj = traffic_table()
+        tname, tj = traffic_table(wl)
         key = dom.split(" (+")[0]
         traffic = tj[key]["hbm_bytes_per_launch"] if key in tj else None
+        ab = _hip.PROFILE_BYTES.get(dom)
+        alg_bytes = ab[0] / ab[1] if ab else None
         # `achieved` / `frac` = what the matrix cores EXECUTE (<= peak by construction).  The Winograd kernels execute 4/9 of the
         # algorithmic FLOPs of the convolution they implement (2*M*N*K of the direct form); that algorithmic rate is
         # reported beside it as `algorithmic_tflops`, and its ratio to the peak as `speedup_vs_direct_roofline` (may exceed 1:
@@ -283,10 +311,15 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
                     "unit": "TFLOP/s", "frac": round(exe * alg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "algorithmic_tflops": round(alg_tf, 2),
                     "speedup_vs_direct_roofline": round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "frac_vs_direct_roofline": round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),      # SURVEY 8d's definition: algorithmic FLOPs / time / peak
                     "executed_share_of_algorithmic_flops": round(exe, 4),
+                    "algorithmic_bytes_per_launch": None if alg_bytes is None else round(alg_bytes),
+                    "traffic_ratio": None if (alg_bytes is None or traffic is None) else round(traffic / alg_bytes, 3),
                     "note": ("Winograd F(2x2,3x3): the kernel executes 4/9 of the direct convolution's FLOPs on the matrix cores (exact "
                              "fp32); achieved/frac count executed FLOPs, algorithmic_tflops the direct convolution's") if exe < 1 else None,
-                    "traffic_note": f"HBM+fabric bytes per launch, PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/{tname}",
+                    "traffic_note": (f"HBM+fabric bytes per launch of this kernel in the same bench command, PMC passes (FETCH_SIZE, WRITE_SIZE: "
+                                     f"they cannot run inside the timed region) tracked as profiles/{tname}; traffic_ratio = traffic / "
+                                     f"algorithmic bytes (x + y + residual + U read / written once)") if tname else None,
                     "clock_note": ("peak = 2.4 GHz figure; in-kernel s_memtime/s_memrealtime stamps show the shader clock at 1.75-1.9 GHz while the "
                                    "Winograd convolution runs and 2.1 GHz under its weight gradient (DESIGN.md section 3, profiles/r03_wino_clock.txt)")
                                   if exe < 1 else None,
@@ -310,6 +343,8 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
             roofline["hbm"] = {"bound": "hbm", "kernel": hk, "achieved": round(by / th / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3,
                                "unit": "GB/s", "frac": round(by / th / 1e12 / PEAK_HBM_TBS, 4),
                                "traffic": tj[hk]["hbm_bytes_per_launch"] if hk in tj else None,
+                               "traffic_ratio": round(tj[hk]["hbm_bytes_per_launch"] / (by / nh), 3) if hk in tj else None,
+                               "traffic_source": f"profiles/{tname}" if (tname and hk in tj) else None,
                                "launches_per_step": nh // 2, "avg_launch_ms": round(th / nh * 1e3, 4),
                                "bytes_per_launch": round(by / nh), "ms_per_step": round(th / 2 * 1e3, 3),
                                "all_hbm_kernels": {k[4:]: {"gbs": round(v[0] / v[1] / 1e9, 1), "ms_per_step": round(v[1] / 2 * 1e3, 3),
@@ -335,13 +370,22 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
             tmax = torch.tensor([ms_off], device=device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             ms_off = float(tmax.item())
+        # where inside backward every bucket is handed to the collective (events on the compute stream, one traced step)
+        trainer.reducer.trace = []
+        one_step()
+        pts = trainer.reducer.launch_points_ms()
+        trainer.reducer.trace = None
+        barrier()
         mg = {"backend": dist.get_backend() if dist.is_initialized() else None,
               "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
               "devices_visible": torch.cuda.device_count(),
               "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
               "ms_per_step_no_allreduce": round(ms_off, 3), "allreduce_exposed_ms": round(ms_per_step - ms_off, 3),
               "grad_bytes_per_step": 4 * trainer.flat.numel, "buckets": len(trainer.reducer.bounds),
-              "bucket_bytes": 4 * (trainer.reducer.bounds[0][1] - trainer.reducer.bounds[0][0])}
+              "bucket_bytes": 4 * (trainer.reducer.bounds[0][1] - trainer.reducer.bounds[0][0]),
+              "reserved_cus": int(_hip.lib().vd_reserved_cus()), "ready_per_block": bool(_hip.READY_PER_BLOCK),
+              "bucket_launch_ms_after_backward_start": pts[:-1] if pts else None,
+              "backward_ms": pts[-1] if pts else None}
     res["multi_gpu"] = mg
     res["trainer"] = trainer
     return res
@@ -376,7 +420,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VD_BENCH_BACKEND", "nccl")                                  # "nccl" == RCCL on ROCm
-        dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
+        opts = None
+        if backend == "nccl" and os.environ.get("VD_RCCL_HIGH_PRIORITY", "0") != "0":
+            # opt-in: RCCL's kernels on a high-priority stream (a bucket's all-reduce is dispatched ahead of queued compute workgroups as
+            # soon as a CU frees up).  Off by default: on one MI355X (1-rank RCCL) it changed nothing with all CUs in use and cost
+            # 12 ms per step together with reserved CUs -- to be re-measured on a multi-GPU node
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank, pg_options=opts)
 
     from v_diffusion import _hip
     _hip.lib()
@@ -414,14 +464,18 @@ def main():
                      "config": {"workload": r2["name"] + " full train step (BASELINE configs[3]); second figure: DDIM-50 CFG w=1 sampling",
                                 "global_batch": world * 128, "per_gpu_batch": 128, "resolution": 64, "final_loss": round(r2["final_loss"], 5)},
                      "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
-                     "roofline": None if rf is None else {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_tflops",
-                                                                              "speedup_vs_direct_roofline", "launches_per_step", "avg_launch_ms",
-                                                                              "flops_per_launch", "share_of_matmul_time", "whole_step")}}
+                     "roofline": None if rf is None else {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                                              "algorithmic_tflops", "speedup_vs_direct_roofline",
+                                                                              "frac_vs_direct_roofline", "algorithmic_bytes_per_launch",
+                                                                              "traffic_ratio", "traffic_note", "launches_per_step",
+                                                                              "avg_launch_ms", "flops_per_launch", "share_of_matmul_time",
+                                                                              "whole_step")}}
         if rf is not None:
             top = sorted(rf["all_matmul_kernels"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:8]
             secondary["roofline"]["top_matmul_kernels"] = dict(top)
             if "hbm" in rf:
-                secondary["roofline"]["hbm"] = {k: rf["hbm"][k] for k in ("kernel", "achieved", "unit", "frac", "traffic", "ms_per_step")}
+                secondary["roofline"]["hbm"] = {k: rf["hbm"][k] for k in ("kernel", "achieved", "unit", "frac", "traffic", "traffic_ratio",
+                                                                             "traffic_source", "bytes_per_launch", "ms_per_step")}
         if not args.no_sample:
             r2.pop("trainer")
             gc.collect()

@@ -32,6 +32,14 @@ extern "C" {
 int         vd_version(void);
 const char* vd_last_error(void);
 
+/* Compute units the PERSISTENT convolution launches (vd_conv3x3_wino, vd_conv3x3_dgrad_wino43: one workgroup per CU holding all of its
+ * LDS and registers for the whole launch, 0.1-1.5 ms) leave free: their grids are sized CUs - n.  A data-parallel rank sets it so that
+ * the RCCL kernels of a gradient bucket launched from inside backward (reference DDP overlap, train.py:141-148) find a free CU at once
+ * instead of waiting for a persistent launch to tail off.  Process-wide, default 0 or the VD_RESERVE_CUS environment variable;
+ * 0 <= n <= CUs - 8; multiples of 8 keep the XCD-aware item order of those kernels.  Returns the previous value, or -1 if refused. */
+int         vd_set_reserved_cus(int32_t n);
+int         vd_reserved_cus(void);
+
 /* ------------------------------------------------------------------ dense contractions (MFMA fp32)
  * One tile engine (v_mfma_f32_32x32x2_f32, LDS-staged, double buffered) behind every
  * matmul-shaped op of the path.  C[z][m][n] = alpha * sum_k A(z,m,k) * B(z,n,k) (+bias[n]) (+R[z][m][n]) (+C) */
@@ -236,6 +244,15 @@ int vd_gn_apply(const float* x, int64_t ldx, const float* stats, const float* ga
                 const float* film, int32_t act, float p_drop, uint64_t seed,
                 int32_t resample, float* y, int64_t ldy,
                 int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G, float* coef, void* stream);
+
+/* vd_gn_coef_from_partials + vd_gn_apply in ONE launch (reference: the same nn.GroupNorm call sites, unet.py:28-30 <- :52,119,123,230):
+ * every workgroup of the apply pass derives the statistics of the groups it touches from the producers' partial sums (part1 / part2:
+ * layout of vd_gemm `stats`, channel-concatenated sources) and the workgroups of pixel chunk 0 write the [nimg][4][C] table `coef`
+ * (NULL: not needed, e.g. inference) that vd_gn_apply_bwd reads. */
+int vd_gn_apply_from_partials(const float* x, int64_t ldx, const float* part1, int32_t C1, int32_t chunks1, const float* part2, int32_t C2,
+                              int32_t chunks2, const float* gamma, const float* beta, const float* film, int32_t act, float p_drop,
+                              uint64_t seed, int32_t resample, float* y, int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t C,
+                              int32_t G, float eps, float* coef, void* stream);
 
 /* backward of vd_gn_apply.  dy is at the OUTPUT resolution of the forward op.
  *   dx (+)= d/dx ; dfilm [nimg][2C] (written) ; dgamma/dbeta (+)= (accumulate_params)

@@ -13,3 +13,13 @@ VD_GEMM_TILE=128 python tests/probe/gemm_shapes.py cifar10 128 > $OUT/gemm_t128.
 python tests/probe/gemm_shapes.py celeba 128 > $OUT/gemm_celeba_natural.txt 2>&1
 tail -20 $OUT/newtests.txt
 head -50 $OUT/gemm_natural.txt
+# 1-GPU cost of the data-parallel levers (1-rank RCCL group, reducer forced on): reserved CUs, readiness per block
+B="python bench.py --steps 20 --warmup 5 --no-sample --no-cpu-baseline --no-secondary --no-extras"
+for rep in 1 2; do
+  for n in 0 8 16 32; do
+    echo "== reserve $n"; VD_BENCH_FORCE_REDUCER=1 VD_RESERVE_CUS=$n MASTER_PORT=$((29600 + n)) $B 2>/dev/null | python -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(j['ms_per_step'], j['multi_gpu'])"
+  done
+  echo "== ready per block"; VD_BENCH_FORCE_REDUCER=1 VD_READY_PER_BLOCK=1 MASTER_PORT=29611 $B 2>/dev/null | python -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(j['ms_per_step'], j['multi_gpu'])"
+  echo "== no reducer"; $B 2>/dev/null | python -c "import sys,json; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(j['ms_per_step'])"
+done > $OUT/dp_levers.txt 2>&1
+cat $OUT/dp_levers.txt

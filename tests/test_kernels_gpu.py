@@ -390,6 +390,18 @@ def test_gn_stats_from_producer_epilogues(H, case):
     H.gn_coef_from_partials(parts, nimg, HW, gamma, beta, film, coef_b)
     H.gn_apply(buf, Ct, None, gamma, beta, film, 1, 0.0, 0, H.RS_NONE, y_b, Ct, nimg, Hh, Ww, Ct, coef_b)
     assert torch.equal(coef_a, coef_b) and torch.equal(y_a, y_b)
+    # ... and both in ONE launch (vd_gn_apply_from_partials: every apply workgroup finalises the statistics of its own groups; the sums
+    # run in fp64 in another order than the wave butterfly, so the fp32 results may differ in the last bit)
+    y_c, coef_c = torch.empty_like(buf), torch.full((nimg, 4, Ct), 5.0, device=DEV)
+    H.gn_apply_from_partials(buf, Ct, parts, gamma, beta, film, 1, 0.0, 0, H.RS_NONE, y_c, Ct, nimg, Hh, Ww, Ct, coef_c)
+    assert (coef_c - coef_a).abs().max().item() <= 2e-6 * coef_a.abs().max().item()
+    assert (y_c - y_a).abs().max().item() <= 4e-6 * max(y_a.abs().max().item(), 1.0)
+    for rs in (H.RS_DOWN, H.RS_UP):          # the resampling forms of the apply pass, table not requested
+        Ho, Wo = (Hh // 2, Ww // 2) if rs == H.RS_DOWN else (Hh * 2, Ww * 2)
+        y_d, y_e = torch.empty(nimg, Ho, Wo, Ct, device=DEV), torch.empty(nimg, Ho, Wo, Ct, device=DEV)
+        H.gn_apply(buf, Ct, None, gamma, beta, film, 1, 0.0, 0, rs, y_d, Ct, nimg, Hh, Ww, Ct, coef_b)
+        H.gn_apply_from_partials(buf, Ct, parts, gamma, beta, film, 1, 0.0, 0, rs, y_e, Ct, nimg, Hh, Ww, Ct, None)
+        assert (y_e - y_d).abs().max().item() <= 4e-6 * max(y_d.abs().max().item(), 1.0)
 
 
 @pytest.mark.parametrize("rs", [0, 1, 2])
@@ -774,7 +786,7 @@ def test_wino_forms_in_subprocess(H, wide):
                         "conv3x3_wino_forward_stats_dgrad or wino_conv_at_bench_launches"],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "19 passed" in r.stdout, r.stdout[-500:]      # 12 geometry cases + 7 bench launches
+    assert " passed" in r.stdout and "27 passed" in r.stdout, r.stdout[-500:]      # 12 geometry cases + 7 + 8 bench launches (WINO_BENCH + CELEBA_MIXED)
 
 
 # ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) convolution

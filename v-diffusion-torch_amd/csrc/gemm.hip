@@ -41,6 +41,8 @@ struct GemmArgs {
     long long sBias;                          // bias offset per batch entry zb
     int group_S;                              // GROUPED launches: split-K slabs per entry
     int lgW, lgHW;                            // log2 of W and H*W when both are powers of two, else -1 (shift/mask instead of divisions)
+    long long a_kblk, b_kblk;                 // GROUPED COL operands stored in K BLOCKS of 16 rows: row k of an entry sits at (k >> 4) * kblk + (k & 15) * ld
+                                              // (0: plain [K][ld] rows).  Lets 36 same-shape operands interleave block by block: [K/16][36][16][ld]
 };
 
 // timing-probe bits: compiled out of the product library (VD_PROBE_BUILD is a constant: every `PB(p) & bit` branch folds away);
@@ -481,7 +483,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
         const int q = j * 4 + wave;
         if (AK == VD_COL) {
             const int kk = q * A_RPP + lane / A_LPR, cm = (lane % A_LPR) * 4;
-            voA[j] = (m0 + cm < p.M) ? (unsigned)(kk * (int)p.lda + cm) * 4u : OOB;
+            const int rowoff = (GROUPED && p.a_kblk) ? (kk >> 4) * (int)p.a_kblk + (kk & 15) * (int)p.lda : kk * (int)p.lda;
+            voA[j] = (m0 + cm < p.M) ? (unsigned)(rowoff + cm) * 4u : OOB;
             kcA[j] = kk; mkA[j] = 0;
         } else {
             const int row = q * RRPP + lane / RLPR;
@@ -512,7 +515,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
             const int kk = q * B_RPP + lane / B_LPR, cn = (lane % B_LPR) * 4;
             kcB[j] = kk;
             const bool ok = (BK == VD_IM2COL) ? (ci0 + cn < p.Cin) : (n0 + cn < p.N);
-            voB[j] = ok ? (unsigned)(kk * (int)p.ldb + cn) * 4u : OOB;
+            const int rowoff = (GROUPED && BK == VD_COL && p.b_kblk) ? (kk >> 4) * (int)p.b_kblk + (kk & 15) * (int)p.ldb : kk * (int)p.ldb;
+            voB[j] = ok ? (unsigned)(rowoff + cn) * 4u : OOB;
             if (BK == VD_IM2COL) pix_yx(p, kt_begin * KT + kk, by[j], bx[j]);
             else by[j] = bx[j] = 0;
         }
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
             int kwidth;
             if (AK == VD_IM2COL) { aoff = (long long)((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.lda + c0; kwidth = p.Cin - c0; }
             else if (AK == VD_ROW) { aoff = (long long)kt * KT; kwidth = p.K - kt * KT; }
-            else { aoff = (long long)kt * KT * p.lda; kwidth = p.K - kt * KT; }
+            else { aoff = (GROUPED && p.a_kblk) ? (long long)kt * (KT / 16) * p.a_kblk : (long long)kt * KT * p.lda; kwidth = p.K - kt * KT; }
             P.pA = Ablk + aoff;
 #pragma unroll
             for (int j = 0; j < AIT; ++j) {
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
             if (BK == VD_ROW) {
                 if (AK == VD_IM2COL) { boff = (long long)tapA * p.Cin + ccA * KT; kwidth = p.Cin - ccA * KT; }
                 else { boff = (long long)kt * KT; kwidth = p.K - kt * KT; }
-            } else { boff = (long long)kt * KT * p.ldb + tapoffB; kwidth = p.K - kt * KT; }
+            } else { boff = ((GROUPED && BK == VD_COL && p.b_kblk) ? (long long)kt * (KT / 16) * p.b_kblk : (long long)kt * KT * p.ldb) + tapoffB; kwidth = p.K - kt * KT; }
             P.pB = Bblk + boff;
             const int dy = tapN / 3 - 1, dx = tapN % 3 - 1;
             if (BK == VD_IM2COL && p.lgW >= 0) {
@@ -1264,9 +1268,21 @@ extern "C" size_t vd_gemm_grouped_wgrad_ws_bytes(int32_t count, int32_t M, int32
     return (size_t)count * (splitk > 1 ? splitk : 1) * ((size_t)M * N + M) * sizeof(float);
 }
 
+/* a_kblk / b_kblk != 0: the A / B rows of every entry are stored in blocks of 16 K rows, block b of an entry at A[e] + b * a_kblk (see
+ * GemmArgs): the 36 planes of the F(4x4,3x3) weight gradient interleave block by block so that its transform pass writes one contiguous run */
+int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
+                               int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws,
+                               size_t ws_bytes, void* stream, int64_t a_kblk, int64_t b_kblk);
+
 extern "C" int vd_gemm_grouped_wgrad(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
                                      int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws,
                                      size_t ws_bytes, void* stream) {
+    return vd_gemm_grouped_wgrad_kblk(A, B, C, colsum, count, M, N, K, lda, ldb, ldc, splitk, ws, ws_bytes, stream, 0, 0);
+}
+
+int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
+                               int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws,
+                               size_t ws_bytes, void* stream, int64_t a_kblk, int64_t b_kblk) {
     VD_REQUIRE(A && B && C && count > 0 && count <= VD_GROUP_MAX, "vd_gemm_grouped_wgrad: 1..%d entries (got %d)", VD_GROUP_MAX, count);
     VD_REQUIRE(M > 0 && N > 0 && K > 0 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc >= N,
                "vd_gemm_grouped_wgrad: M, N, lda, ldb must be multiples of 4 (M=%d N=%d)", M, N);
@@ -1282,6 +1298,9 @@ extern "C" int vd_gemm_grouped_wgrad(const float* const* A, const float* const* 
     a.A = A[0]; a.B = B[0];
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N; a.ldr = 0; a.nh = 1;
     a.alpha = 1.f; a.lgW = a.lgHW = -1; a.probe = 0;
+    a.a_kblk = a_kblk; a.b_kblk = b_kblk;
+    VD_REQUIRE(a_kblk >= 0 && b_kblk >= 0 && a_kblk % 4 == 0 && b_kblk % 4 == 0 && 2 * a_kblk + 16 * lda + 128 < 0x70000000LL / 4 &&
+               2 * b_kblk + 16 * ldb + 128 < 0x70000000LL / 4, "vd_gemm_grouped_wgrad: K-block strides outside the LDS-DMA kernel's range");
     // (the grouped launch exists only on the LDS-DMA kernel: VD_GEMM_LEGACY does not apply to it)
     VD_REQUIRE(dma_in_range(a), "vd_gemm_grouped_wgrad: operands outside the LDS-DMA kernel's range (alignment / row pitch)");
     const int tile = choose_tile(M, N, false, (long long)count * S, 0);

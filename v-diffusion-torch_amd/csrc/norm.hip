@@ -224,6 +224,14 @@ struct ApplyArgs {
     const float* x; long long ldx; const float* coef; int has_norm; int act; float p_drop; unsigned long long seed;
     int resample; float* y; long long ldy; int nimg, H, W, C;
 };
+// statistics straight from the partial sums a producer epilogue left behind (vd_gn_apply_from_partials): every workgroup of the apply pass
+// derives the (mean, rstd) of the groups it touches itself -- a few KB of L2-resident partials per image -- instead of a separate
+// 5-microsecond launch per norm in front of it (73 per CIFAR UNet pass); the workgroups of pixel chunk 0 also write the [4][C] table
+// the backward pass reads
+struct PartArgs {
+    const float* p1; int C1, ch1; const float* p2; int C2, ch2; int G; float eps;
+    const float* gamma; const float* beta; const float* film; float* coef_out;
+};
 
 __device__ __forceinline__ f32x4 fwd_val(const ApplyArgs& p, f32x4 v, int pix, int c4, f32x4 sc, f32x4 of, int b) {
     if (p.has_norm) v = v * sc + of;
@@ -245,19 +253,69 @@ constexpr int APIX = 64;     // output pixels per workgroup of the apply kernels
 
 // grid (pixel chunks, images, channel splits): a thread keeps ONE float4 of channels for all its pixels, so the
 // coefficient table is read once per thread and the loop has no 64-bit index arithmetic
-__global__ __launch_bounds__(256) void gn_apply_kernel(const ApplyArgs p, int Cb) {
+template <bool FROM_PARTS>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const ApplyArgs p, int Cb, const PartArgs q) {
+    __shared__ double ps[FROM_PARTS ? 2 : 1][FROM_PARTS ? 1024 : 1];     // per-channel sums of the workgroup's channel range
+    __shared__ float gst[FROM_PARTS ? 2 : 1][FROM_PARTS ? 256 : 1];       // (mean, rstd) of its groups
     const int b = blockIdx.y, c0 = blockIdx.z * Cb;
-    const int vecs = min(Cb, p.C - c0) >> 2, rows = 256 / vecs;
+    const int cbw = min(Cb, p.C - c0);
+    const int vecs = cbw >> 2, rows = 256 / vecs;
     const int r = threadIdx.x / vecs, c4 = c0 + 4 * (threadIdx.x % vecs);
-    if (r >= rows) return;
     const int Ho = p.resample == VD_RS_DOWN ? p.H >> 1 : (p.resample == VD_RS_UP ? p.H << 1 : p.H);
     const int Wo = p.resample == VD_RS_DOWN ? p.W >> 1 : (p.resample == VD_RS_UP ? p.W << 1 : p.W);
     const int p0 = blockIdx.x * APIX, np = min(APIX, Ho * Wo - p0);
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f};
-    if (p.has_norm) {
-        const float* cf = p.coef + (long long)b * 4 * p.C;
-        sc = *reinterpret_cast<const f32x4*>(cf + c4);
-        of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
+    if (FROM_PARTS) {
+        // (the launcher gives a workgroup whole groups: Cb % (C / G) == 0)
+        const int C = p.C, cg = C / q.G;
+        for (int cl = threadIdx.x; cl < cbw; cl += 256) {
+            const int c = c0 + cl;
+            const bool first = c < q.C1;
+            const int Cs = first ? q.C1 : q.C2, cs = first ? c : c - q.C1, chunks = first ? q.ch1 : q.ch2;
+            const float* src = (first ? q.p1 : q.p2) + (long long)b * chunks * 2 * Cs + cs;
+            double s1 = 0.0, s2 = 0.0;
+            for (int ch = 0; ch < chunks; ++ch) { s1 += (double)src[(long long)ch * 2 * Cs]; s2 += (double)src[(long long)ch * 2 * Cs + Cs]; }
+            ps[0][cl] = s1; ps[1][cl] = s2;
+        }
+        __syncthreads();
+        const int ng = cbw / cg;
+        for (int g = threadIdx.x; g < ng; g += 256) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int c = g * cg; c < (g + 1) * cg; ++c) { s1 += ps[0][c]; s2 += ps[1][c]; }
+            const double n = (double)cg * (double)p.H * (double)p.W;
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gst[0][g] = (float)mean; gst[1][g] = (float)(1.0 / sqrt(var + (double)q.eps));
+        }
+        __syncthreads();
+        if (r >= rows) return;
+        f32x4 nr, nm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c4 + j, g = (c - c0) / cg;
+            const float mean = gst[0][g], rstd = gst[1][g];
+            float s_ = rstd * q.gamma[c];
+            float o_ = q.beta[c] - mean * s_;
+            if (q.film) {
+                const float shift = q.film[(long long)b * 2 * C + c], scale = q.film[(long long)b * 2 * C + C + c];
+                s_ *= (1.f + scale);
+                o_ = o_ * (1.f + scale) + shift;
+            }
+            sc[j] = s_; of[j] = o_; nr[j] = rstd; nm[j] = -mean * rstd;
+        }
+        if (blockIdx.x == 0 && r == 0 && q.coef_out) {
+            float* o = q.coef_out + (long long)b * 4 * C + c4;
+            *reinterpret_cast<f32x4*>(o) = sc; *reinterpret_cast<f32x4*>(o + C) = of;
+            *reinterpret_cast<f32x4*>(o + 2 * C) = nr; *reinterpret_cast<f32x4*>(o + 3 * C) = nm;
+        }
+    } else {
+        if (r >= rows) return;
+        if (p.has_norm) {
+            const float* cf = p.coef + (long long)b * 4 * p.C;
+            sc = *reinterpret_cast<const f32x4*>(cf + c4);
+            of = *reinterpret_cast<const f32x4*>(cf + p.C + c4);
+        }
     }
     const float* ximg = p.x + (long long)b * p.H * p.W * p.ldx;
     float* yimg = p.y + (long long)b * Ho * Wo * p.ldy;
@@ -746,8 +804,40 @@ extern "C" int vd_gn_apply(const float* x, int64_t ldx, const float* stats, cons
     const long long Wo = resample == VD_RS_DOWN ? W / 2 : (resample == VD_RS_UP ? W * 2 : W);
     const int Cba = pick_cb(C);
     VD_REQUIRE(C % Cba == 0 && Cba % 4 == 0 && Cba <= 1024 && nimg <= 65535, "vd_gn_apply: cannot split C=%d / nimg=%d", C, nimg);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((Ho * Wo + APIX - 1) / APIX), nimg, C / Cba), dim3(256), 0, st, p, Cba);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)((Ho * Wo + APIX - 1) / APIX), nimg, C / Cba), dim3(256), 0, st, p, Cba, PartArgs{});
     VD_LAUNCH_CHECK("gn_apply_kernel");
+    return 0;
+}
+
+/* vd_gn_coef_from_partials + vd_gn_apply in ONE launch: y = resample(dropout(act(FiLM(GroupNorm(x))))) with the statistics taken from the
+ * partial sums of up to two channel-concatenated producers (layout of vd_gemm `stats` / vd_conv3x3 `stats_part`), and the [nimg][4][C]
+ * coefficient table written for the backward pass (coef may be NULL at inference).  Reference: nn.GroupNorm unet.py:28-30 + its call sites. */
+extern "C" int vd_gn_apply_from_partials(const float* x, int64_t ldx, const float* part1, int32_t C1, int32_t chunks1, const float* part2,
+                                         int32_t C2, int32_t chunks2, const float* gamma, const float* beta, const float* film, int32_t act,
+                                         float p_drop, uint64_t seed, int32_t resample, float* y, int64_t ldy, int32_t nimg, int32_t H,
+                                         int32_t W, int32_t C, int32_t G, float eps, float* coef, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VD_REQUIRE(x && y && part1 && gamma && beta, "vd_gn_apply_from_partials: null operand");
+    VD_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && C % G == 0 && C1 + C2 == C && C1 > 0 && chunks1 > 0,
+               "vd_gn_apply_from_partials: bad channel split C=%d C1=%d C2=%d G=%d", C, C1, C2, G);
+    VD_REQUIRE(C2 == 0 || (part2 && chunks2 > 0), "vd_gn_apply_from_partials: second source incomplete");
+    VD_REQUIRE(resample != VD_RS_DOWN || (H % 2 == 0 && W % 2 == 0), "vd_gn_apply_from_partials: odd size cannot be average-pooled");
+    VD_REQUIRE(vd_aligned16(x) && vd_aligned16(y) && (!coef || vd_aligned16(coef)), "vd_gn_apply_from_partials: operands must be 16-byte aligned");
+    ApplyArgs p = {x, ldx, coef, 1, act, p_drop, seed, resample, y, ldy, nimg, H, W, C};
+    PartArgs q = {part1, C1, chunks1, part2, C2, chunks2, G, eps, gamma, beta, film, coef};
+    const long long Ho = resample == VD_RS_DOWN ? H / 2 : (resample == VD_RS_UP ? H * 2 : H);
+    const long long Wo = resample == VD_RS_DOWN ? W / 2 : (resample == VD_RS_UP ? W * 2 : W);
+    // channel range of a workgroup: whole groups, a multiple of 4 channels, at most 1024
+    const int cg = C / G;
+    int Cba = pick_cb(C);
+    if (Cba % cg) {
+        Cba = 0;
+        for (int k = G; k >= 1; --k) if (G % k == 0 && (k * cg) % 4 == 0 && k * cg <= 1024) { Cba = k * cg; break; }
+    }
+    VD_REQUIRE(Cba > 0 && C % Cba == 0 && Cba % 4 == 0 && Cba % cg == 0 && Cba <= 1024 && Cba / cg <= 256 && nimg <= 65535,
+               "vd_gn_apply_from_partials: cannot split C=%d into whole-group channel ranges", C);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)((Ho * Wo + APIX - 1) / APIX), nimg, C / Cba), dim3(256), 0, st, p, Cba, q);
+    VD_LAUNCH_CHECK("gn_apply_kernel<from partials>");
     return 0;
 }
 

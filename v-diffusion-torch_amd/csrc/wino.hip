@@ -919,7 +919,7 @@ extern "C" int vd_conv3x3_wino(const float* xin, int64_t ldx, const float* U, co
                "vd_conv3x3_wino: unsupported geometry nimg=%d H=%d W=%d Cin=%d Cout=%d (use vd_conv3x3)", nimg, H, W, Cin, Cout);
     VD_REQUIRE(vd_aligned16(xin) && vd_aligned16(U) && vd_aligned16(y) && (!res || vd_aligned16(res)) && (!bias || vd_aligned16(bias)),
                "vd_conv3x3_wino: operands must be 16-byte aligned");
-    const int ncu = vd_cu_count();            // persistent workgroups: one per CU (the LDS footprint admits no second one)
+    const int ncu = vd_persistent_cus();      // persistent workgroups: one per CU (the LDS footprint admits no second one), minus the reserved CUs
     {
         // wide form (128-tile items, ~5 % faster per unit of work: same-box A/B in tests/perf_wino.py) wherever its items fill the
         // residency rounds at least as well as the 64-tile items do: rounds x 2 x 0.95 against the narrow form's rounds

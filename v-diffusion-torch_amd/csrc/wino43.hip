@@ -495,9 +495,14 @@ __device__ __forceinline__ void a6(const f32x4 (&y)[4], f32x4 (&o)[6]) {
     o[5] = y[3];
 }
 
+// V / dM layout: K-blocked [T/16][36][16][C] (1: a transform block's 36 planes land in one contiguous run, the grouped GEMMs step through K
+// blocks: vd_gemm_grouped_wgrad_kblk) or plane-major [36][T][C] (0: same-box A/B builds only, tests/probe/r04_pass4.sh)
+#ifndef VD_W43_KBLOCK
+#define VD_W43_KBLOCK 1
+#endif
 struct WgT43 {
     const float* x; long long ldx; const float* dy; long long lddy;
-    float* V; float* dM;                       // [36][T][Cin], [36][T][Cout]
+    float* V; float* dM;                       // [T/16][36][16][Cin], [T/16][36][16][Cout]: blocks of 16 tiles, the 36 planes of a block adjacent
     int nimg, H, W, Cin, Cout, TW, TPI, T;     // tiles per row / image / in all
 };
 
@@ -532,7 +537,8 @@ __global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43
             bt6(col, o);                                            // V[a][b] = sum_p B^T[a][p] R[p][b]
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                *reinterpret_cast<f32x4*>(p.V + ((long long)(6 * a + b) * p.T + tile) * p.Cin + c4) = o[a];
+                *reinterpret_cast<f32x4*>(p.V + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
+                                                                : ((long long)(6 * a + b) * p.T + tile)) * p.Cin + c4) = o[a];
         }
     } else {
         if (c4 >= p.Cout) return;
@@ -552,7 +558,8 @@ __global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43
             a6(col, o);                                             // dM[a][b] = sum_u A[a][u] R[u][b]
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                *reinterpret_cast<f32x4*>(p.dM + ((long long)(6 * a + b) * p.T + tile) * p.Cout + c4) = o[a];
+                *reinterpret_cast<f32x4*>(p.dM + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
+                                                                 : ((long long)(6 * a + b) * p.T + tile)) * p.Cout + c4) = o[a];
         }
     }
 }
@@ -611,7 +618,8 @@ Wg43Plan wg43_plan(int nimg, int H, int W, int Cin, int Cout) {
     // split-K slabs: whole residency rounds of the chip (vd_gemm_grouped_wgrad_auto_split), fp32 accumulation chains of at most ~1536
     // tiles (the error of dw grows with the chain length), at most 24 slabs
     g.S = vd_gemm_grouped_wgrad_auto_split(36, Cout, Cin, g.T, (g.T + 1535) / 1536, 24);
-    g.v_f = (size_t)36 * g.T * Cin; g.m_f = (size_t)36 * g.T * Cout; g.u_f = (size_t)36 * Cout * Cin; g.cs_f = (size_t)36 * Cout;
+    const size_t T16 = ((size_t)g.T + 15) / 16 * 16;       // (V / dM are stored in blocks of 16 tiles)
+    g.v_f = (size_t)36 * T16 * Cin; g.m_f = (size_t)36 * T16 * Cout; g.u_f = (size_t)36 * Cout * Cin; g.cs_f = (size_t)36 * Cout;
     g.gemm_bytes = vd_gemm_grouped_wgrad_ws_bytes(36, Cout, Cin, g.S);
     g.ok = true;
     return g;
@@ -651,7 +659,7 @@ extern "C" int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const floa
     const long long items = (long long)a.ngrp * a.ncb;
     VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_dgrad_wino43: too many work items");
     a.nitems = (int)items;
-    const int ncu = vd_cu_count();
+    const int ncu = vd_persistent_cus();      // (one workgroup per CU, minus the CUs reserved for other streams: vd_set_reserved_cus)
     const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (W == 16) hipLaunchKernelGGL((wino43_dgrad_kernel<4>), grid, blk, 0, st, a);
@@ -727,9 +735,11 @@ static int wgrad43_impl(const float* xin, int64_t ldx, const float* dy, int64_t 
     if (phases & 2) {
         const float* A[36]; const float* B[36]; float* C[36]; float* colsum[36];
         for (int e = 0; e < 36; ++e) {
-            A[e] = dM + (size_t)e * g.T * Cout; B[e] = V + (size_t)e * g.T * Cin; C[e] = dU + (size_t)e * Cout * Cin; colsum[e] = cs + (size_t)e * Cout;
+            A[e] = dM + (size_t)e * (VD_W43_KBLOCK ? 16 : g.T) * Cout; B[e] = V + (size_t)e * (VD_W43_KBLOCK ? 16 : g.T) * Cin;
+            C[e] = dU + (size_t)e * Cout * Cin; colsum[e] = cs + (size_t)e * Cout;
         }
-        const int rc = vd_gemm_grouped_wgrad(A, B, C, colsum, 36, Cout, Cin, g.T, Cout, Cin, Cin, g.S, gws, g.gemm_bytes, stream);
+        const int rc = vd_gemm_grouped_wgrad_kblk(A, B, C, colsum, 36, Cout, Cin, g.T, Cout, Cin, Cin, g.S, gws, g.gemm_bytes, stream,
+                                                  VD_W43_KBLOCK ? 36LL * 16 * Cout : 0, VD_W43_KBLOCK ? 36LL * 16 * Cin : 0);
         if (rc) return rc;
         g_last43w = g.S;
     }

@@ -35,6 +35,8 @@ class GemmDesc(C.Structure):
 _SIGNATURES = {
     "vd_version": (C.c_int, []),
     "vd_last_error": (C.c_char_p, []),
+    "vd_set_reserved_cus": (C.c_int, [_i32]),
+    "vd_reserved_cus": (C.c_int, []),
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_last_tile": (C.c_int, []),
     "vd_gemm_grouped_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32]),
@@ -72,6 +74,8 @@ _SIGNATURES = {
     "vd_gn_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "vd_gn_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "vd_gn_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vd_gn_apply_from_partials": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _i32,
+                                            _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vd_gn_apply_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _u64, _i32, _vp, _i64, _vp, _i64, _i32,
                                   _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "vd_gn_bwd_last_kernel": (C.c_int, []),
@@ -171,7 +175,15 @@ _ws_cache = {}
 # rocprofv3 kernel names: gemm_dma_kernel<BM, BN, a_kind, b_kind, splitk, KT, TR> with kinds 0 = ROW, 1 = COL, 2 = IM2COL
 # (TR = transposed-accumulator epilogue, taken by launches without output statistics).
 PROFILE = None
+PROFILE_BYTES = {}            # kernel name -> [algorithmic bytes (operands read + written once) summed over its recorded launches, launches]
 _KIND = {0: "ROW", 1: "COL", 2: "IM2COL"}
+
+
+def _note_bytes(name, nbytes):
+    if PROFILE is not None:
+        e = PROFILE_BYTES.setdefault(name, [0.0, 0])
+        e[0] += float(nbytes)
+        e[1] += 1
 
 
 class _Timed:
@@ -309,6 +321,7 @@ def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres
                 t.name = f"wino_conv_wide_kernel<{k // 2000}, {(k // 2) % 1000}, {'true' if k & 1 else 'false'}>"
             else:
                 t.name = t.name.format(tw=k // 2000, ns=(k // 2) % 1000, st="true" if k & 1 else "false")
+            _note_bytes(t.name, 4.0 * (nimg * H * W * (Cin + Cout + (Cout if res is not None else 0)) + 16 * Cout * Cin))
 
 
 WINO43 = os.environ.get("VD_WINO43", "1") != "0"  # A/B switch: 0 keeps the input gradients on F(2x2,3x3)
@@ -335,6 +348,7 @@ def conv3x3_dgrad_wino43(dy, lddy, U43, dx, lddx, nimg, H, W, Cin, Cout):
     with _TimedName(f"wino43_dgrad_kernel<{W // 4}>", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3_dgrad_wino43(ptr(dy), lddy, ptr(U43), ptr(dx), lddx, nimg, H, W, Cin, Cout, stream()),
                "vd_conv3x3_dgrad_wino43")
+    _note_bytes(f"wino43_dgrad_kernel<{W // 4}>", 4.0 * (nimg * H * W * (Cin + Cout) + 36 * Cout * Cin))
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):
@@ -365,6 +379,10 @@ WGRAD_STREAM = os.environ.get("VD_WGRAD_STREAM", "1") != "0"
 # slab count of the grouped 1x1 / linear weight gradients from vd_gemm_grouped_wgrad_auto_split (whole residency rounds: -0.5 ms per CIFAR
 # step against the fixed 1024-workgroup rule, same-box A/B); VD_GROUPED_AUTO_SPLIT=0: that rule
 GROUPED_AUTO_SPLIT = os.environ.get("VD_GROUPED_AUTO_SPLIT", "1") != "0"
+# data-parallel runs (a gradient reducer listens to backward): report gradients ready after every residual / attention block (1) or at
+# UNet-level boundaries only (0: fewer, larger grouped weight-gradient launches; buckets leave in bursts)
+GN_FOLD = os.environ.get("VD_GN_FOLD", "1") != "0"       # A/B switch: 0 = statistics finalize and apply as two launches
+READY_PER_BLOCK = os.environ.get("VD_READY_PER_BLOCK", "0") != "0"
 WINO43_WGRAD = os.environ.get("VD_WINO43_WGRAD", "1") != "0"   # A/B switch: 0 keeps every weight gradient on F(2x2,3x3)
 # fewest 4x4-output tiles (= K of the 36 GEMMs) it is picked for: 512 = 8x8 images at batch 128 (256 -> 256: x1.17, 768 -> 768: x1.41 over the fused
 # F(2x2,3x3) kernel, same-box A/B tests/perf_wgrad43.py); the library serves nothing below 512
@@ -389,6 +407,9 @@ def conv3x3_wgrad_wino43(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cou
         _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 1, stream()), "vd_conv3x3_wgrad_wino43_phase")
     with _TimedName("wino43_wgrad_gemm (gemm_dma_kernel<..., grouped> x 36 planes)", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 2, stream()), "vd_conv3x3_wgrad_wino43_phase")
+    # (its operands are the transformed images: 36 planes of [tiles][Cin] and [tiles][Cout], read once, + the 36 x Cout x Cin result)
+    _note_bytes("wino43_wgrad_gemm (gemm_dma_kernel<..., grouped> x 36 planes)",
+                4.0 * (36.0 * nimg * (H // 4) * (W // 4) * (Cin + Cout) + 36.0 * Cout * Cin))
     with _TimedName("wino43_wgrad_finish_kernel", 0.0):
         _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 4, stream()), "vd_conv3x3_wgrad_wino43_phase")
 
@@ -479,6 +500,16 @@ def gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, l
     hw_out = H * W // 4 if resample == RS_DOWN else (H * W * 4 if resample == RS_UP else H * W)
     with _TimedBytes("gn_apply_kernel" if gamma is not None else "gn_apply_kernel (resample)", 4.0 * nimg * Cc * (H * W + hw_out)):
         _gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G)
+
+
+def gn_apply_from_partials(x, ldx, parts, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G=32, eps=1e-6):
+    """statistics from the producers' partial sums + apply in one launch (vd_gn_apply_from_partials); parts: [(part, C, chunks)] x 1 or 2"""
+    (p1, c1, k1), (p2, c2, k2) = parts[0], (parts[1] if len(parts) > 1 else (None, 0, 0))
+    hw_out = H * W // 4 if resample == RS_DOWN else (H * W * 4 if resample == RS_UP else H * W)
+    with _TimedBytes("gn_apply_kernel", 4.0 * nimg * Cc * (H * W + hw_out)):
+        _check(lib().vd_gn_apply_from_partials(ptr(x), ldx, ptr(p1), c1, k1, ptr(p2), c2, k2, ptr(gamma), ptr(beta), ptr(film), int(act),
+                                               float(p_drop), int(seed), resample, ptr(y), ldy, nimg, H, W, Cc, G, eps, ptr(coef), stream()),
+               "vd_gn_apply_from_partials")
 
 
 def _gn_apply(x, ldx, stats, gamma, beta, film, act, p_drop, seed, resample, y, ldy, nimg, H, W, Cc, coef, G=32):

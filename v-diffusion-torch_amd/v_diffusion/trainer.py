@@ -19,6 +19,7 @@ MI355X-first choices
     the reference's >= 5 foreach passes.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -26,6 +27,10 @@ import torch.distributed as dist
 from . import _hip
 
 BUCKET_BYTES = 32 << 20
+# CUs the persistent convolution kernels leave to RCCL in data-parallel runs unless VD_RESERVE_CUS says otherwise.  0: measured on one MI355X
+# (1-rank RCCL, reducer on) reserving 8 CUs costs 6 % of the step -- the dominant kernel's 2048 work items need a ninth
+# round on 248 CUs -- while an unreserved bucket waits at most one persistent launch (< 0.8 ms) and only the last bucket's wait is exposed.
+RESERVE_CUS_DP = 0
 
 
 def completion_order(model):
@@ -125,13 +130,31 @@ class GradReducer:
         params = dict(flat.model.named_parameters())
         self.end_of = {k: flat.offsets[k] + params[k].numel() for k in flat.order}
         self.works, self.next_bucket = [], 0
+        self.trace = None
 
     def start(self):
         self.works, self.next_bucket = [], 0
+        if self.trace is not None:                 # (bench.py self-check: where inside backward does every bucket leave?)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace = [ev]
 
     def _launch(self, lo, hi):
         t = self.flat.g[lo:hi]
+        if self.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                            # on the compute stream: the point of backward at which this bucket's gradients were final
+            self.trace.append(ev)
         self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def launch_points_ms(self):
+        """[ms after the start of backward at which bucket i was handed to the collective] + [ms at which backward ended] of the last
+        traced step (``self.trace = []`` before the step switches tracing on); synchronises."""
+        if not self.trace or len(self.trace) < 2:
+            return None
+        torch.cuda.synchronize()
+        t0 = self.trace[0]
+        return [round(t0.elapsed_time(e), 3) for e in self.trace[1:]]
 
     def ready(self, name):
         """Called by the backward pass when ``name`` (and everything before it in completion order) is final."""
@@ -148,6 +171,10 @@ class GradReducer:
         while self.next_bucket < len(self.bounds):
             self._launch(*self.bounds[self.next_bucket])
             self.next_bucket += 1
+        if self.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                            # end of backward on the compute stream (before the waits below)
+            self.trace.append(ev)
         for w in self.works:
             w.wait()
         self.works = []
@@ -225,6 +252,10 @@ class HotPathTrainer:
         self.leader = dist.get_global_rank(group, 0) if (world_size > 1 and group is not None) else 0
         self.is_leader = world_size == 1 or (dist.get_rank() == self.leader if dist.is_initialized() else rank == 0)
         self._flag_group = None
+        if world_size > 1 and os.environ.get("VD_RESERVE_CUS") is None and RESERVE_CUS_DP:
+            # RCCL's kernels must find a CU while the persistent convolution kernels hold theirs for a whole launch (one workgroup per
+            # CU, all of its LDS): leave RESERVE_CUS_DP of them out of those grids (vd_set_reserved_cus; 1-GPU cost in DESIGN section 4)
+            _hip.lib().vd_set_reserved_cus(RESERVE_CUS_DP)
         if world_size > 1:                                                            # DDP ctor broadcast (train.py:148)
             dist.broadcast(self.flat.p, src=self.leader, group=group)
             if self.flat.ema is not None:
