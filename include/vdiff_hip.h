@@ -140,22 +140,38 @@ int vd_wino_set_probe(unsigned long long* buf);
 #endif
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
 /* ---- input gradient of the same convolution as Winograd F(4x4, 3x3) (csrc/wino43.hip): 36 multiplies per 4x4 output tile where
- * F(2x2,3x3) needs 64 -- 1.78x fewer matrix-core cycles, ~7x the rounding error of a direct fp32 sum, which is why it serves
- * gradients only (stated bound: per-tensor relative L2 <= 1e-4) and never the forward pass (autograd of modules.py:141-144).
+ * F(2x2,3x3) needs 64 -- 1.78x fewer matrix-core cycles; with the classic interpolation points {0, +-1, +-2, inf} used here ~7x the
+ * rounding error of a direct fp32 sum, an order of magnitude inside the stated bound on gradients (per-tensor relative L2 <= 1e-4;
+ * autograd of modules.py:141-144).
  *   U43 = vd_wino43_pack(w): (G rot180(w[co][ci]) G^T)[36] in the order the kernel's lanes read it, vd_wino43_u_floats(Cout, Cin) floats;
  *   dx[nimg][H][W][:Cin] = vd_conv3x3_dgrad_wino43(dy[nimg][H][W][:Cout], U43)   every element written, no accumulation.
  * _supported: 1 for 32x32 images, 64-wide images with H % 16 == 0 and 16x16 images in multiples of four (four per work item),
  * Cout % 8 == 0, Cin % 32 == 0, 16-byte rows, tensors < 2 GiB;
  * otherwise call vd_conv3x3_wino with the rotated F(2x2,3x3) image.  vd_wino43_last_kernel: tiles per row (4 / 8 / 16) of the calling
- * thread's last launch = the instantiation wino43_dgrad_kernel<TWT> (profiling / test aid). */
+ * thread's last launch, negative for vd_conv3x3_wino43_fwd = the instantiation wino43_conv_kernel<TWT, FWD> (profiling / test aid). */
 int vd_conv3x3_dgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t lddy, int64_t lddx);
 size_t vd_wino43_u_floats(int32_t Cout, int32_t Cin);
 int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const float* U43, float* dx, int64_t lddx, int32_t nimg, int32_t H, int32_t W,
                             int32_t Cin, int32_t Cout, void* stream);
 int vd_wino43_last_kernel(void);
 int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, void* stream);
-/* all tensors in one launch: items_dev = [n][8] int64 {w, U43, 0, Cout, Cin, 0, 0, first block}; a tensor takes (Cin/32)*(Cout/8) blocks */
+/* all tensors in one launch: items_dev = [n][8] int64 {w, U43, fwd, Cout, Cin, 0, 0, first block}; fwd = 0: the input-gradient image,
+ * (Cin/32)*(Cout/8) blocks; fwd = 1: the forward image of vd_wino43_pack_fwd, (Cout/32)*(Cin/8) blocks */
 int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
+/* ---- FORWARD pass of the same convolution through F(4x4,3x3) (replaces F.conv2d of modules.py:141-144 for the residual-block
+ * convolutions unet.py:121,125 on the 16x16 / 32x32 / 64-wide layers), with the interpolation points {0, +-3/4, +-3/2, inf}: every
+ * coefficient of the data and output transforms is a dyadic rational, exact in fp32, and the whole-network output error is ~2x that of
+ * the F(2x2,3x3) forward, inside the stated 2e-5 bound (tests/probe/wino_err_sim.py; measured: tests/test_unet_gpu.py).
+ *   U43f = vd_wino43_pack_fwd(w): (G w[co][ci] G^T)[36] in the kernel's lane order, vd_wino43_u_floats(Cout, Cin) floats;
+ *   y[nimg][H][W][:Cout] = conv3x3(x[..][:Cin], w) + bias (+ res)     bias / res may be NULL; every element written
+ *   stats_part (or NULL): GroupNorm partial sums of y as [nimg][chunks][2][Cout] with ONE CHUNK PER (image, work item):
+ *   vd_conv3x3_wino43_fwd_chunk_rows(H, W) pixels per chunk (H*W for 16x16 and 32x32 images, 16*W for 64-wide ones).
+ * _supported: the geometries of the input gradient (above) with Cin % 8 == 0, Cout % 32 == 0; otherwise call vd_conv3x3_wino. */
+int vd_conv3x3_wino43_fwd_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t ldy, int64_t ldres);
+int vd_wino43_pack_fwd(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43f, void* stream);
+int vd_conv3x3_wino43_fwd_chunk_rows(int32_t H, int32_t W);
+int vd_conv3x3_wino43_fwd(const float* xin, int64_t ldx, const float* U43f, const float* bias, const float* res, int64_t ldres, float* y,
+                          int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* stats_part, void* stream);
 /* weight (and bias) gradient of the same convolution through F(4x4,3x3), UNFUSED: one HBM-bound pass writes dM = A dY A^T and V = B^T d B
  * ([36][tiles][channels], 2.25x the size of dY / x each), the 36 GEMMs over the tile index run as one vd_gemm_grouped_wgrad launch (1.78x fewer
  * MFMA cycles than vd_conv3x3_wgrad_wino), a small kernel folds G^T . G into OIHW; the bias gradient is the column sum of plane (1,1).

@@ -365,6 +365,57 @@ def test_wino43_dgrad_at_bench_launches(H, case):
     print(f"wino43 dgrad {case[:5]}: rel-L2 {rel:.2e}, max err {err:.2e} of {sc:.2f}")
 
 
+@pytest.mark.parametrize("case", [c for c in WINO_ALL if c[2] in (16, 32, 64)], ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}to{c[4]}")
+def test_wino43_fwd_at_bench_launches(H, case):
+    """vd_conv3x3_wino43_fwd (Winograd F(4x4,3x3) with the interpolation points {0, +-3/4, +-3/2, inf}: what the forward pass runs for the
+    16x16 ... 64x64 layers since round 4) at the bench launches, B = 128: output + bias + residual and the GroupNorm partial sums it
+    emits (one chunk per image and work item) against fp64 on the device; bitwise reproducible, also without statistics.  Held to the
+    bound of the F(2x2,3x3) forward test (1.5e-5 of the output scale; measured 4-7e-6) -- the whole-network bound is checked by
+    tests/test_unet_gpu.py with this kernel in the path."""
+    nimg, Hh, Ww, Cin, Cout, _ = case
+    HW = Hh * Ww
+    assert H.WINO43_FWD and H.wino43_fwd_supported(nimg, Hh, Ww, Cin, Cout, Cin, Cout, Cout)
+    x = F.silu(_rand((nimg, Hh, Ww, Cin), 1))
+    w = _rand((Cout, Cin, 3, 3), 2, (9 * Cin) ** -0.5)
+    b = _rand((Cout,), 3)
+    res = _rand((nimg, Hh, Ww, Cout), 4)
+    u43f = torch.empty(H.lib().vd_wino43_u_floats(Cout, Cin), device=DEV)
+    H.wino43_pack_fwd(w, Cout, Cin, u43f)
+    y = torch.full((nimg, Hh, Ww, Cout), 7.0, device=DEV)
+    part = torch.full((H.stats_part_numel(nimg, HW, Cout),), 7.0, device=DEV)
+    H.conv3x3_wino43_fwd(x, Cin, u43f, b, y, Cout, nimg, Hh, Ww, Cin, Cout, res=res, ldres=Cout, stats_part=part)
+    assert H.lib().vd_wino43_last_kernel() == -(Ww // 4)
+    rows = H.wino43_fwd_chunk_rows(Hh, Ww)
+    assert rows == (16 * Ww if Ww == 64 else HW)
+    stats = torch.empty(nimg, 32, 2, device=DEV)
+    H.gn_stats_from_partials([(part, Cout, HW // rows)], nimg, HW, stats)
+    y2 = torch.empty_like(y)
+    H.conv3x3_wino43_fwd(x, Cin, u43f, b, y2, Cout, nimg, Hh, Ww, Cin, Cout, res=res, ldres=Cout)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2), "statistics-free launch differs / not bitwise reproducible"
+    ref = _conv_fp64_gpu(x, w, b) + res.double()
+    scale = max(ref.abs().max().item(), 1.0)
+    err = (y.double() - ref).abs().max().item()
+    rel = ((y.double() - ref).norm() / ref.norm()).item()
+    assert err <= 1.5e-5 * scale and rel <= 2e-6, f"F(4,3) forward max err {err:.3e} (scale {scale:.2f}), rel-L2 {rel:.3e}"
+    grp = ref.reshape(nimg, HW, 32, Cout // 32).permute(0, 2, 1, 3).reshape(nimg, 32, -1)
+    mean, var = grp.mean(-1), grp.var(-1, unbiased=False)
+    assert (stats[..., 0].double() - mean).abs().max().item() <= 2e-6 * max(mean.abs().max().item(), 1.0)
+    rstd = 1 / torch.sqrt(var + 1e-6)
+    assert ((stats[..., 1].double() - rstd) / rstd).abs().max().item() <= 5e-6
+    for i in (0, nimg - 1):
+        xi = x[i:i + 1].permute(0, 3, 1, 2).double().cpu()
+        ri = F.conv2d(xi, w.double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 1) + res[i:i + 1].double().cpu()
+        assert (ri - ref[i:i + 1].cpu()).abs().max().item() <= 1e-11 * max(ri.abs().max().item(), 1.0)
+    # without bias / residual, output written into a channel slice of a wider buffer (ld > C: the virtual concat)
+    wide = torch.full((nimg, Hh, Ww, Cout + 32), 5.0, device=DEV)
+    H.conv3x3_wino43_fwd(x, Cin, u43f, None, wide[..., 32:], Cout + 32, nimg, Hh, Ww, Cin, Cout)
+    torch.cuda.synchronize()
+    ref0 = ref - res.double() - b.double()
+    assert (wide[..., 32:].double() - ref0).abs().max().item() <= 1.5e-5 * scale and float(wide[..., :32].min()) == 5.0 == float(wide[..., :32].max())
+    print(f"wino43 fwd {case[:5]}: max err {err:.2e} (scale {scale:.1f}), rel-L2 {rel:.2e}")
+
+
 @pytest.mark.parametrize("case", WINO_ALL, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}x{c[3]}to{c[4]}")
 def test_wino43_wgrad_at_bench_launches(H, case):
     """The weight (+ bias) gradient H.conv3x3_wgrad runs for the 8x8 ... 64x64 layers at B = 128 since round 3: F(4x4,3x3), unfused
@@ -446,34 +497,41 @@ def test_cifar_train_step_b64_vs_oracle():
     def spy_wino(*a, **k):
         wino_calls[0] += 1
         return real_wino(*a, **k)
-    w43_calls, attn_bwd_calls = [0], [0]
+    w43_calls, attn_bwd_calls, w43f_calls = [0], [0], [0]
 
     def spy_w43(*a, **k):
         w43_calls[0] += 1
         return real_w43(*a, **k)
 
+    def spy_w43f(*a, **k):
+        w43f_calls[0] += 1
+        return real_w43f(*a, **k)
+
     def spy_attn_bwd(*a, **k):
         attn_bwd_calls[0] += 1
         return real_attn_bwd(*a, **k)
-    real_conv, real_wgrad, real_wino, real_w43, real_attn_bwd = (_hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino,
-                                                                 _hip.conv3x3_dgrad_wino43, _hip.attn_bwd)
-    _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43, _hip.attn_bwd = (spy_conv, spy_wgrad, spy_wino,
-                                                                                                       spy_w43, spy_attn_bwd)
+    real_conv, real_wgrad, real_wino, real_w43, real_attn_bwd, real_w43f = (_hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino,
+                                                                            _hip.conv3x3_dgrad_wino43, _hip.attn_bwd, _hip.conv3x3_wino43_fwd)
+    (_hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43, _hip.attn_bwd,
+     _hip.conv3x3_wino43_fwd) = (spy_conv, spy_wgrad, spy_wino, spy_w43, spy_attn_bwd, spy_w43f)
     try:
         loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
         loss.mean().backward()
         torch.cuda.synchronize()
     finally:
-        _hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43, _hip.attn_bwd = (real_conv, real_wgrad, real_wino,
-                                                                                                           real_w43, real_attn_bwd)
+        (_hip.conv3x3, _hip.conv3x3_wgrad, _hip.conv3x3_wino, _hip.conv3x3_dgrad_wino43, _hip.attn_bwd,
+         _hip.conv3x3_wino43_fwd) = (real_conv, real_wgrad, real_wino, real_w43, real_attn_bwd, real_w43f)
     # head dim 256: the shipped policy keeps the training step's attention on the three launches; VD_FUSED_ATTN=2 (set by
     # test_cifar_train_step_b64_fused_attention_hd256 together with the expected count) sends all 18 blocks through the fused backward
     assert attn_bwd_calls[0] == int(__import__("os").environ.get("VD_EXPECT_FUSED_BWD", "0")), attn_bwd_calls
     code = lambda tr, kt: ((tr * 100 + kt) * 1000 + 128) * 1000 + 128
     if _hip.WINO:           # every residual-block convolution of this network is served by the Winograd kernels
         # 54 forward launches + 54 input gradients, of which the 16 at 32x32 and the 18 at 16x16 take the F(4x4,3x3) kernel (VD_WINO43=0: none)
+        # (round 4: the same 34 layers run their FORWARD pass through the F(4x4,3x3) kernel too; VD_WINO43_FWD=0: none)
         n43 = 34 if _hip.WINO43 else 0
-        assert (wino_calls[0], w43_calls[0]) == (108 - n43, n43) and not any(k == "conv" for k, _ in seen), (wino_calls, w43_calls, sorted(seen))
+        n43f = 34 if _hip.WINO43_FWD else 0
+        assert (wino_calls[0], w43_calls[0], w43f_calls[0]) == (108 - n43 - n43f, n43, n43f) and not any(k == "conv" for k, _ in seen), \
+            (wino_calls, w43_calls, w43f_calls, sorted(seen))
         # B = 64: the 32x32 (4096 tiles) and 16x16 layers (1024) take the F(4x4,3x3) weight gradient, 8x8 (256 tiles) the fused F(2x2,3x3) kernel
         want = {("wgrad_wino43", 32), ("wgrad_wino43", 16), ("wgrad_wino", 4)} if _hip.WINO43_WGRAD else {("wgrad_wino", 16), ("wgrad_wino", 8), ("wgrad_wino", 4)}
         assert {k for k in seen if k[0].startswith("wgrad_wino")} == want, sorted(seen)
@@ -557,7 +615,7 @@ def test_celeba_train_step_b8_vs_oracle():
     gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), 50, "v", "fixed_medium", "snr_trunc",
                                        "mse", intp_frac=0.3, w_guide=1.0, p_uncond=0.0)
     wino_calls, fused = [0], [0]
-    real_wino, real_attn, real_w43 = _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43
+    real_wino, real_attn, real_w43, real_w43f = _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43, _hip.conv3x3_wino43_fwd
 
     def spy_wino(*a, **k):
         wino_calls[0] += 1
@@ -569,13 +627,17 @@ def test_celeba_train_step_b8_vs_oracle():
     def spy_w43(*a, **k):
         wino_calls[0] += 1
         return real_w43(*a, **k)
-    _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43 = spy_wino, spy_attn, spy_w43
+
+    def spy_w43f(*a, **k):
+        wino_calls[0] += 1
+        return real_w43f(*a, **k)
+    _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43, _hip.conv3x3_wino43_fwd = spy_wino, spy_attn, spy_w43, spy_w43f
     try:
         loss = gd.train_loss(model, x0.to(DEV), t.to(DEV), y.to(DEV), noise.to(DEV))
         loss.mean().backward()
         torch.cuda.synchronize()
     finally:
-        _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43 = real_wino, real_attn, real_w43
+        _hip.conv3x3_wino, _hip.attn_bwd, _hip.conv3x3_dgrad_wino43, _hip.conv3x3_wino43_fwd = real_wino, real_attn, real_w43, real_w43f
     if _hip.WINO:
         assert wino_calls[0] == 2 * 2 * 36, wino_calls            # 36 residual blocks x 2 convolutions x (forward + input gradient), both Winograd orders
     if _hip.FUSED_ATTN != "0":

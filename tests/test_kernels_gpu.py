@@ -944,6 +944,51 @@ def test_conv3x3_dgrad_wino43(H, case):
     assert rel <= 1.5e-5 and err <= 6e-5 * ref.abs().max().item(), f"wino43 dgrad rel-L2 {rel:.3e}, max err {err:.3e} of {ref.abs().max().item():.2f}"
 
 
+# forward pass through the same kernel (FWD = true: dyadic interpolation points, bias / residual / GroupNorm partials in the epilogue).
+# Cases as above with the roles of the channel counts swapped: GEMM K = Cin (multiple of 8), columns = Cout (multiple of 32)
+@pytest.mark.parametrize("case", WINO43_CASES)
+def test_conv3x3_wino43_fwd(H, case):
+    """vd_conv3x3_wino43_fwd == F.conv2d + bias + residual (fp64 truth), GroupNorm partials == statistics of what was written,
+    bitwise reproducible, padding channels of y untouched, ld > C on x / y / res.  Per-layer bound: the F(2x2,3x3) forward tests'
+    slack (8 x torch's own fp32-vs-fp64 error of the same layer, floor 4e-6)."""
+    nimg, Hh, Ww, Cout, Cin, ex, ey = case                     # (the table's Cin % 32 column is this kernel's Cout)
+    HW = Hh * Ww
+    assert H.lib().vd_conv3x3_wino43_fwd_supported(nimg, Hh, Ww, Cin, Cout, Cin + ex, Cout + ey, Cout + ey) == 1
+    x = rnd(nimg, Cin, Hh, Ww, seed=1)
+    w, b = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=3)
+    res = rnd(nimg, Cout, Hh, Ww, seed=4)
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    ref32 = F.conv2d(x, w, b, padding=1) + res
+    u43f = torch.empty(H.lib().vd_wino43_u_floats(Cout, Cin), device=DEV)
+    H.wino43_pack_fwd(w.to(DEV), Cout, Cin, u43f)
+    y = torch.full((nimg, Hh, Ww, Cout + ey), 5.0, device=DEV)
+    part = torch.full((H.stats_part_numel(nimg, HW, Cout),), 7.0, device=DEV)
+    H.conv3x3_wino43_fwd(nhwc(x, Cin + ex), Cin + ex, u43f, b.to(DEV), y, Cout + ey, nimg, Hh, Ww, Cin, Cout, res=nhwc(res, Cout + ey),
+                         ldres=Cout + ey, stats_part=part)
+    assert H.lib().vd_wino43_last_kernel() == -(Ww // 4)
+    y2 = torch.full_like(y, 5.0)
+    H.conv3x3_wino43_fwd(nhwc(x, Cin + ex), Cin + ex, u43f, b.to(DEV), y2, Cout + ey, nimg, Hh, Ww, Cin, Cout, res=nhwc(res, Cout + ey),
+                         ldres=Cout + ey)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2), "not bitwise reproducible / statistics-free launch differs"
+    if ey:
+        assert (y[..., Cout:] == 5.0).all(), "padding channels of y were written"
+    close(from_nhwc(y, Cout), ref64, ref32, slack=8.0, floor=4e-6, name="wino43 forward")
+    if Cout % 32 == 0 and (Cout // 32) >= 1 and Cout % 32 == 0 and Cout >= 32:
+        rows = H.wino43_fwd_chunk_rows(Hh, Ww)
+        stats = torch.empty(nimg, 32, 2, device=DEV)
+        H.gn_stats_from_partials([(part, Cout, HW // rows)], nimg, HW, stats)
+        g = from_nhwc(y, Cout).double().cpu().reshape(nimg, 32, -1)          # statistics of what was WRITTEN
+        mean, var = g.mean(-1), g.var(-1, unbiased=False)
+        close(stats[..., 0], mean, None, floor=2e-6, name="mean")
+        close(stats[..., 1], 1 / torch.sqrt(var + 1e-6), None, floor=5e-6, name="rstd")
+    # no bias, no residual
+    y3 = torch.empty(nimg, Hh, Ww, Cout, device=DEV)
+    H.conv3x3_wino43_fwd(nhwc(x, Cin + ex), Cin + ex, u43f, None, y3, Cout, nimg, Hh, Ww, Cin, Cout)
+    close(from_nhwc(y3, Cout), ref64 - res.double() - b.double().view(1, -1, 1, 1), ref32 - res - b.view(1, -1, 1, 1), slack=8.0, floor=4e-6,
+          name="wino43 forward (plain)")
+
+
 def test_conv3x3_dgrad_wino43_rejects_unsupported(H):
     f = H.lib().vd_conv3x3_dgrad_wino43_supported
     assert f(2, 16, 16, 32, 32, 32, 32) == 0             # 16x16 images are served four at a time

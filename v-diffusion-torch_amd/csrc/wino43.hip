@@ -1,11 +1,16 @@
-// wino43.hip -- INPUT GRADIENT of the 3x3 / stride 1 / pad 1 convolution as Winograd F(4x4, 3x3) on the fp32 matrix cores, NHWC.
-// Reference op: autograd of modules.Conv2d -> F.conv2d (modules.py:141-144 <- unet.py:121,125) with respect to its input.
+// wino43.hip -- the 3x3 / stride 1 / pad 1 convolution as Winograd F(4x4, 3x3) on the fp32 matrix cores, NHWC: its INPUT GRADIENT
+// (round 3), its FORWARD pass (round 4) and, unfused, its WEIGHT GRADIENT (further down).
+// Reference op: modules.Conv2d -> F.conv2d (modules.py:141-144 <- unet.py:121,125) and its autograd.
 //
-// Why a second Winograd order, and why only for gradients: F(4x4,3x3) needs 36 multiplies per 4x4 output tile and (ci, co) pair
-// where F(2x2,3x3) (wino.hip) needs 16 per 2x2 tile -- 2.25 instead of 4 per output, 1.78x fewer matrix-core cycles again -- at
-// ~7x the rounding error of a direct fp32 sum (measured against fp64: tests).  That is too coarse for the forward pass (stated
-// bound 2e-5 on the UNet output) and an order of magnitude inside the 1e-4 relative bound on gradients, so the forward
-// convolutions stay on F(2x2,3x3) and this kernel serves the input gradients of the layers whose geometry it covers.
+// Why a second Winograd order: F(4x4,3x3) needs 36 multiplies per 4x4 output tile and (ci, co) pair where F(2x2,3x3) (wino.hip) needs
+// 16 per 2x2 tile -- 2.25 instead of 4 per output, 1.78x fewer matrix-core cycles again -- at a larger rounding error that depends on the
+// interpolation points.  With the classic points {0, +-1, +-2, inf} a layer carries ~7x the error of a direct fp32 sum: an order of
+// magnitude inside the 1e-4 relative bound on gradients, so the INPUT GRADIENT uses them (FWD = false).  The FORWARD pass (FWD = true) uses
+// {0, +-3/4, +-3/2, inf} -- every coefficient of B^T and A^T a dyadic rational, exact in fp32 -- with which the whole-network output error
+// is ~2x that of the F(2x2,3x3) forward (fp32 simulation of both networks against the reference's own fp32 evaluation,
+// tests/probe/wino_err_sim.py: CIFAR 4.2e-6 vs 2.0e-6, CelebA 5.7e-6 vs 2.3e-6 max-abs; classic points 8.8e-6 / 9.2e-6) and stays inside
+// the stated 2e-5 bound on the UNet output (measured on MI355X: tests/test_unet_gpu.py).  VD_WINO43_FWD=0 keeps
+// the forward convolutions on F(2x2,3x3).
 //
 //   U[xi][n][k]   = (G rot180(w[k][n]) G^T)[xi]        xi = 6a+b in 0..35, n = conv input channel (GEMM column), k = conv output
 //                                                     channel (GEMM K)                            (vd_wino43_pack*, per weight update)
@@ -50,6 +55,10 @@ struct Args43 {
     int items_per_img;                        // 1 (32x32) or H/16 (64 wide); 16x16 images: FOUR IMAGES per item (tile groups = nimg / 4)
     int ngrp;                                 // tile groups (64 tiles each)
     int ncb, nitems;
+    // forward pass only (FWD): y = conv + bias (+ res), GroupNorm partial sums of y per (image, chunk of an item's pixels, channel)
+    const float* bias; const float* res; long long ldr;
+    float* stats;                             // [nimg][chunks_per_img][2][N] or NULL: chunk = the pixels one work item holds of one image
+    int chunks_per_img;                       // 1 (32x32, 16x16) or H/16 (64 wide)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
@@ -79,9 +88,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #ifndef VD_W43_DPS
 #define VD_W43_DPS 1          /* DMA pieces of tile kt+2 issued per step behind the barrier */
 #endif
-template <int HALF, typename T>
+// DY: the dyadic point set {0, +-3/4, +-3/2, inf} of the forward pass (the rows of bt6 below) instead of the classic {0, +-1, +-2, inf}
+template <int HALF, bool DY, typename T>
 __device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
-    if (HALF == 0) {
+    if (DY) {
+        if (HALF == 0) {
+            const T e1 = d[4] - 2.25f * d[2], f1 = 0.75f * d[3] - 1.6875f * d[1];
+            o0 = 1.265625f * d[0] + (d[4] - 2.8125f * d[2]);
+            o1 = e1 + f1;
+            o2 = e1 - f1;
+        } else {
+            const T e2 = d[4] - 0.5625f * d[2], f2 = 1.5f * d[3] - 0.84375f * d[1];
+            o0 = e2 + f2;
+            o1 = e2 - f2;
+            o2 = 1.265625f * d[1] + (d[5] - 2.8125f * d[3]);
+        }
+    } else if (HALF == 0) {
         const T t = d[4] - 4.f * d[2], u = d[3] - 4.f * d[1];
         o0 = 4.f * d[0] + (d[4] - 5.f * d[2]);
         o1 = t + u;
@@ -94,8 +116,19 @@ __device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
     }
 }
 // all six outputs (the column pass)
-template <typename T>
+template <bool DY, typename T>
 __device__ __forceinline__ void bt_full(const T (&r)[6], T (&v)[6]) {
+    if (DY) {
+        const T e1 = r[4] - 2.25f * r[2], f1 = 0.75f * r[3] - 1.6875f * r[1];
+        const T e2 = r[4] - 0.5625f * r[2], f2 = 1.5f * r[3] - 0.84375f * r[1];
+        v[0] = 1.265625f * r[0] + (r[4] - 2.8125f * r[2]);
+        v[1] = e1 + f1;
+        v[2] = e1 - f1;
+        v[3] = e2 + f2;
+        v[4] = e2 - f2;
+        v[5] = 1.265625f * r[1] + (r[5] - 2.8125f * r[3]);
+        return;
+    }
     const T t = r[4] - 4.f * r[2], u = r[3] - 4.f * r[1], c = r[4] - r[2], e = r[3] - r[1];
     v[0] = 4.f * r[0] + (r[4] - 5.f * r[2]);
     v[1] = t + u;
@@ -105,29 +138,30 @@ __device__ __forceinline__ void bt_full(const T (&r)[6], T (&v)[6]) {
     v[5] = 4.f * r[1] + (r[5] - 5.f * r[3]);
 }
 // the two channels of a lane: f32x2 in, transform per channel (scalar build) or on the pair (packed build)
-template <int HALF>
+template <int HALF, bool DY>
 __device__ __forceinline__ void bt_half2(const f32x2 (&d)[6], f32x2& o0, f32x2& o1, f32x2& o2) {
 #if VD_W43_PACKED
-    bt_half<HALF, f32x2>(d, o0, o1, o2);
+    bt_half<HALF, DY, f32x2>(d, o0, o1, o2);
 #else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float dj[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
         float a, b, c;
-        bt_half<HALF, float>(dj, a, b, c);
+        bt_half<HALF, DY, float>(dj, a, b, c);
         o0[j] = a; o1[j] = b; o2[j] = c;
     }
 #endif
 }
+template <bool DY>
 __device__ __forceinline__ void bt_full2(const f32x2 (&r)[6], f32x2 (&v)[6]) {
 #if VD_W43_PACKED
-    bt_full<f32x2>(r, v);
+    bt_full<DY, f32x2>(r, v);
 #else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float rj[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
         float vj[6];
-        bt_full<float>(rj, vj);
+        bt_full<DY, float>(rj, vj);
 #pragma unroll
         for (int b = 0; b < 6; ++b) v[b][j] = vj[b];
     }
@@ -138,8 +172,9 @@ __device__ __forceinline__ void bt_full2(const f32x2 (&r)[6], f32x2 (&v)[6]) {
 // 16x16 images: the item's patch image stacks its four images vertically with ONE shared zero row between neighbours (rows 17 i are the
 // halo of image i-1 below and of image i above: 69 rows instead of 72), and the column classes keep only the slots that exist (x + 1 in
 // 0..17: classes 0, 1 have five slots, classes 2, 3 four) -- 19 slots per row, 42 KB per stage: the same footprint as a 32x32 image.
-template <int TWT>
-__global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
+// FWD: the forward pass -- dyadic interpolation points, bias / residual / GroupNorm partial sums in the epilogue; else the input gradient
+template <int TWT, bool FWD>
+__global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
     constexpr bool QUAD = TWT == 4;
     constexpr int RUN = TWT + 1;                           // slots of one column class in a pixel row (QUAD: of classes 0 and 1)
     constexpr int RUNS = QUAD ? 4 * RUN - 2 : 4 * RUN;     // slots of a pixel row that hold pixels
@@ -155,7 +190,7 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
     constexpr int LGT = TWT == 4 ? 2 : TWT == 8 ? 3 : 4;
     static_assert((4 * RP * 16) % 256 == (TWT * 16) % 256 || (QUAD && (4 * RP * 16) % 256 == 192), "row pitch leaves bank conflicts");
     static_assert(2 * STAGE * 4 <= 163840, "stages exceed the LDS");
-    static_assert(8 * 16 * 64 * 16 <= 2 * STAGE * 4, "epilogue exchange area exceeds the stages");
+    static_assert(8 * 16 * 64 * 16 + 8 * 4 * 8 * 4 <= 2 * STAGE * 4, "epilogue exchange + statistics area exceeds the stages");
     __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -264,7 +299,7 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
                     else d[pr] = *(const volatile __attribute__((address_space(3))) f32x2*)((const __attribute__((address_space(3))) float*)sa + poff(pr, q));
                 }
                 if (VD_W43_EXP >= 2 && VD_W43_EXP <= 4) { Rn[0][q] = d[1]; Rn[1][q] = d[2]; Rn[2][q] = d[3]; }
-                else bt_half2<HALF>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
+                else bt_half2<HALF, FWD>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
             }
         };
         int cb = 0, grp = 0;
@@ -304,7 +339,7 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
                     if (VD_W43_EXP >= 2 && VD_W43_EXP <= 4) {
 #pragma unroll
                         for (int b = 0; b < 6; ++b) V[b] = R[a][b];
-                    } else bt_full2(R[a], V);
+                    } else bt_full2<FWD>(R[a], V);
 #pragma unroll
                     for (int b = 0; b < 6; ++b) {
                         const int xl = 6 * a + b;
@@ -345,6 +380,11 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
             // pass PT[u][v]; it hands the channel block it does not finish (1 - HALF) to its partner wave through LDS and
             // finishes block HALF.  lane (li, lq): tile tl, channels 32 cb + 16 blk + 4 lq .. +3
             f32x4* xch = reinterpret_cast<f32x4*>(smem);            // [wave][k = 4u+v][lane]; the stages are dead (last barrier)
+            // (forward kernel: the lane coordinates are re-derived here instead of staying live across the K loop -- its dyadic transforms
+            //  need the registers; mbcnt = the lane id)
+            const int lane_e = FWD ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : lane;
+            const int li_e = lane_e & 15, lq_e = lane_e >> 4;
+            const int tl_e = 16 * tg + li_e, tyl_e = tl_e >> LGT, tx_e = tl_e & (TWT - 1);
             f32x4 Y[4][4];
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
@@ -356,25 +396,33 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
                                 m4 = acc[6 * a + 4][blk], m5 = acc[6 * a + 5][blk];
                     const f32x4 p12 = m1 + m2, q12 = m1 - m2, p34 = m3 + m4, q34 = m3 - m4;
                     S[a][0] = m0 + p12 + p34;
-                    S[a][1] = q12 + 2.f * q34;
-                    S[a][2] = p12 + 4.f * p34;
-                    S[a][3] = q12 + 8.f * q34 + m5;
+                    if (FWD) {                  // A^T of {0, +-3/4, +-3/2, inf}: [1 1 1 1 1 0 ; 0 3/4 -3/4 3/2 -3/2 0 ; 0 9/16 9/16 9/4 9/4 0 ; 0 27/64 -27/64 27/8 -27/8 1]
+                        S[a][1] = 0.75f * q12 + 1.5f * q34;
+                        S[a][2] = 0.5625f * p12 + 2.25f * p34;
+                        S[a][3] = 0.421875f * q12 + 3.375f * q34 + m5;
+                    } else {
+                        S[a][1] = q12 + 2.f * q34;
+                        S[a][2] = p12 + 4.f * p34;
+                        S[a][3] = q12 + 8.f * q34 + m5;
+                    }
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     if (HALF == 0) {            // rows a = 0, 1, 2
                         const f32x4 s12 = S[1][v] + S[2][v], d12 = S[1][v] - S[2][v];
-                        Y[0][v] = S[0][v] + s12; Y[1][v] = d12; Y[2][v] = s12; Y[3][v] = d12;
+                        if (FWD) { Y[0][v] = S[0][v] + s12; Y[1][v] = 0.75f * d12; Y[2][v] = 0.5625f * s12; Y[3][v] = 0.421875f * d12; }
+                        else { Y[0][v] = S[0][v] + s12; Y[1][v] = d12; Y[2][v] = s12; Y[3][v] = d12; }
                     } else {                    // rows a = 3, 4, 5
                         const f32x4 s34 = S[0][v] + S[1][v], d34 = S[0][v] - S[1][v];
-                        Y[0][v] = s34; Y[1][v] = 2.f * d34; Y[2][v] = 4.f * s34; Y[3][v] = 8.f * d34 + S[2][v];
+                        if (FWD) { Y[0][v] = s34; Y[1][v] = 1.5f * d34; Y[2][v] = 2.25f * s34; Y[3][v] = 3.375f * d34 + S[2][v]; }
+                        else { Y[0][v] = s34; Y[1][v] = 2.f * d34; Y[2][v] = 4.f * s34; Y[3][v] = 8.f * d34 + S[2][v]; }
                     }
                 }
                 if (pass == 0) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) xch[(wave * 16 + 4 * u + v) * 64 + lane] = Y[u][v];
+                        for (int v = 0; v < 4; ++v) xch[(wave * 16 + 4 * u + v) * 64 + lane_e] = Y[u][v];
                     __syncthreads();
                 }
             }
@@ -383,17 +431,55 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) Y[u][v] += xch[(partner * 16 + 4 * u + v) * 64 + lane];
+                    for (int v = 0; v < 4; ++v) Y[u][v] += xch[(partner * 16 + 4 * u + v) * 64 + lane_e];
             }
             {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const int img = QUAD ? 4 * grp + (tyl >> 2) : grp / p.items_per_img;
+                const int img = QUAD ? 4 * grp + (tyl_e >> 2) : grp / p.items_per_img;
                 const int part = QUAD ? 0 : grp - img * p.items_per_img;
-                const int n0 = cb * TN + 16 * HALF + 4 * lq;
-                const int y0 = QUAD ? 4 * (tyl & 3) : 4 * (NTR * part + tyl), x0 = 4 * tx;
+                const int n0 = cb * TN + 16 * HALF + 4 * lq_e;
+                const int y0 = QUAD ? 4 * (tyl_e & 3) : 4 * (NTR * part + tyl_e), x0 = 4 * tx_e;
                 const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
                 const unsigned ldy_u = (unsigned)p.ldy;
                 const unsigned pix00 = (unsigned)((img * p.H + y0) * p.W + x0);
+                if (FWD) {
+                    // + bias (+ residual: the skip path of the residual block, fetched a tile row at a time), then the GroupNorm partial
+                    // sums of what is written: per lane over its 16 pixels, over the 16 tiles of the wave by shuffles
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0);
+                    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
+                    const unsigned ldr_u = (unsigned)p.ldr;
+                    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        f32x4 rv[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            rv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (p.res) rv[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rrs, (int)(((pix00 + (unsigned)(u * p.W + v)) * ldr_u + (unsigned)n0) * 4u), 0, 0));
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const f32x4 val = (Y[u][v] + bv) + rv[v];
+                            Y[u][v] = val;
+                            s1 += val; s2 += val * val;
+                        }
+                    }
+                    if (p.stats) {
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+                        }
+                        // [wave][lq][8]: behind the exchange area (the stages are dead; the area is read after the barrier below)
+                        float* sarea = smem + 8 * 16 * 64 * 4;
+                        if (li_e == 0) {
+                            *reinterpret_cast<f32x4*>(sarea + (wave * 4 + lq_e) * 8) = s1;
+                            *reinterpret_cast<f32x4*>(sarea + (wave * 4 + lq_e) * 8 + 4) = s2;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -405,6 +491,24 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
                     }
             }
             __syncthreads();                                        // the exchange area is read: the next item's DMA may overwrite it
+            if (FWD && p.stats) {
+                // partial sums of the item: one chunk per image it holds -- the four tile-group waves of a xi half together (one 32x32
+                // image, 16 rows of a 64-wide one) or one wave each (QUAD: a wave's 16 tiles are one 16x16 image).  Fixed order, no atomics.
+                // (read before this wave issues the next item's DMA; the other waves' DMA into this area waits behind the next barrier)
+                const float* sarea = smem + 8 * 16 * 64 * 4;
+                const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                if (tid_e < (QUAD ? 256 : 64)) {
+                    const int tgq = QUAD ? tid_e >> 6 : 0, t6 = tid_e & 63;
+                    const int st = t6 >> 5, ch = t6 & 31, h = ch >> 4, q4 = (ch >> 2) & 3, j = ch & 3;
+                    float v;
+                    if (QUAD) v = sarea[((4 * h + tgq) * 4 + q4) * 8 + 4 * st + j];
+                    else v = (sarea[((4 * h + 0) * 4 + q4) * 8 + 4 * st + j] + sarea[((4 * h + 1) * 4 + q4) * 8 + 4 * st + j]) +
+                             (sarea[((4 * h + 2) * 4 + q4) * 8 + 4 * st + j] + sarea[((4 * h + 3) * 4 + q4) * 8 + 4 * st + j]);
+                    const int img = QUAD ? 4 * grp + tgq : grp / p.items_per_img;
+                    const int chunk = QUAD ? 0 : grp - img * p.items_per_img;
+                    p.stats[(((long long)img * p.chunks_per_img + chunk) * 2 + st) * p.N + cb * TN + ch] = v;
+                }
+            }
         }
     };
     if ((wave >> 2) == 0) run(std::integral_constant<int, 0>{});
@@ -415,20 +519,30 @@ __global__ __launch_bounds__(THREADS) void wino43_dgrad_kernel(const Args43 p) {
 // [n / 32][k / 8][xi][(k % 8) / 2][n % 16][(n % 32) / 16][k % 2].   G = [1/4 0 0 ; -1/6 -1/6 -1/6 ; -1/6 1/6 -1/6 ; 1/24 1/12 1/6 ; 1/24 -1/12 1/6 ; 0 0 1]
 // One 256-thread block per (32 n, 8 k) tile: thread t IS position t of the tile's [kq][n][cb][j] order, so every xi is one
 // coalesced 1 KB run (thread 16 kq + n's four floats are what MFMA lane 16 kq + n reads with one ds_read_b128).  The transform is evaluated in fp64 and rounded once (its coefficients are not dyadic).
-__device__ __forceinline__ void pack43_tile(const float* w, float* U, int Cout, int Cin, int tile) {
-    const int nkt = Cout / KT;
+// fwd: the image of the FORWARD pass instead -- GEMM column n = conv output channel, K = conv input channel, kernel not rotated, and the
+// G of the points {0, +-3/4, +-3/2, inf}:  G = [64/81 0 0 ; -128/243 -32/81 -8/27 ; -128/243 32/81 -8/27 ; 32/243 16/81 8/27 ; 32/243 -16/81 8/27 ; 0 0 1]
+__device__ __forceinline__ void pack43_tile(const float* w, float* U, int Cout, int Cin, int tile, int fwd) {
+    const int nkt = (fwd ? Cin : Cout) / KT;
     const int nb = tile / nkt, kt = tile - nb * nkt;
     const int t = threadIdx.x;
     const int kq = t >> 6, n = (t >> 2) & 15, cbk = (t >> 1) & 1, j = t & 1;
-    const int ci = nb * 32 + 16 * cbk + n, co = kt * KT + 2 * kq + j;
+    const int cn = nb * 32 + 16 * cbk + n, ck = kt * KT + 2 * kq + j;            // GEMM column / K index
+    const int ci = fwd ? ck : cn, co = fwd ? cn : ck;
     const float* src = w + ((long long)co * Cin + ci) * 9;
     double g[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = (double)src[(2 - a) * 3 + (2 - b)];          // rot180
-    const double Gm[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+        for (int b = 0; b < 3; ++b) g[a][b] = (double)(fwd ? src[a * 3 + b] : src[(2 - a) * 3 + (2 - b)]);          // (input gradient: rot180)
+    const double Gc[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const double Gd[6][3] = {{64.0 / 81, 0.0, 0.0}, {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                             {32.0 / 243, 16.0 / 81, 8.0 / 27}, {32.0 / 243, -16.0 / 81, 8.0 / 27}, {0.0, 0.0, 1.0}};
+    double Gm[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Gm[a][c] = fwd ? Gd[a][c] : Gc[a][c];
     double tmp[6][3];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -442,11 +556,11 @@ __device__ __forceinline__ void pack43_tile(const float* w, float* U, int Cout, 
             dst[(6 * a + b) * 256] = (float)(tmp[a][0] * Gm[b][0] + tmp[a][1] * Gm[b][1] + tmp[a][2] * Gm[b][2]);
 }
 
-__global__ __launch_bounds__(256) void wino43_pack_kernel(const float* w, float* U, int Cout, int Cin) {
-    pack43_tile(w, U, Cout, Cin, blockIdx.x);
+__global__ __launch_bounds__(256) void wino43_pack_kernel(const float* w, float* U, int Cout, int Cin, int fwd) {
+    pack43_tile(w, U, Cout, Cin, blockIdx.x, fwd);
 }
 
-// all tensors of a network in one launch; items: 8 x int64 per tensor {w, U, -, Cout, Cin, -, -, first block}
+// all tensors of a network in one launch; items: 8 x int64 per tensor {w, U, forward image (1) or input-gradient image (0), Cout, Cin, -, -, first block}
 __global__ __launch_bounds__(256) void wino43_pack_batched_kernel(const long long* items, int n) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -455,7 +569,7 @@ __global__ __launch_bounds__(256) void wino43_pack_batched_kernel(const long lon
     }
     const long long* it = items + 8 * lo;
     pack43_tile(reinterpret_cast<const float*>(it[0]), reinterpret_cast<float*>(it[1]), (int)it[3], (int)it[4],
-                (int)((long long)blockIdx.x - it[7]));
+                (int)((long long)blockIdx.x - it[7]), (int)it[2]);
 }
 
 // ==================================================================================================================
@@ -662,25 +776,81 @@ extern "C" int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const floa
     const int ncu = vd_persistent_cus();      // (one workgroup per CU, minus the CUs reserved for other streams: vd_set_reserved_cus)
     const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(THREADS);
     hipStream_t st = (hipStream_t)stream;
-    if (W == 16) hipLaunchKernelGGL((wino43_dgrad_kernel<4>), grid, blk, 0, st, a);
-    else if (W == 32) hipLaunchKernelGGL((wino43_dgrad_kernel<8>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((wino43_dgrad_kernel<16>), grid, blk, 0, st, a);
-    VD_LAUNCH_CHECK("wino43_dgrad_kernel");
+    if (W == 16) hipLaunchKernelGGL((wino43_conv_kernel<4, false>), grid, blk, 0, st, a);
+    else if (W == 32) hipLaunchKernelGGL((wino43_conv_kernel<8, false>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((wino43_conv_kernel<16, false>), grid, blk, 0, st, a);
+    VD_LAUNCH_CHECK("wino43_conv_kernel<., false>");
     g_last43 = W / 4;
     return 0;
 }
 
-/* tiles per row (4 / 8 / 16) of the calling thread's last vd_conv3x3_dgrad_wino43 launch = the instantiation wino43_dgrad_kernel<TWT> */
+/* tiles per row (4 / 8 / 16) of the calling thread's last vd_conv3x3_dgrad_wino43 (positive) or vd_conv3x3_wino43_fwd (negative) launch
+ * = the instantiation wino43_conv_kernel<TWT, FWD> */
 extern "C" int vd_wino43_last_kernel(void) { return g_last43; }
 
 extern "C" int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, void* stream) {
     VD_REQUIRE(w_oihw && U43 && Cout % KT == 0 && Cin % TN == 0, "vd_wino43_pack: needs Cout %% 8 == 0 and Cin %% 32 == 0");
-    hipLaunchKernelGGL(wino43_pack_kernel, dim3((unsigned)((Cin / TN) * (Cout / KT))), dim3(256), 0, (hipStream_t)stream, w_oihw, U43, Cout, Cin);
+    hipLaunchKernelGGL(wino43_pack_kernel, dim3((unsigned)((Cin / TN) * (Cout / KT))), dim3(256), 0, (hipStream_t)stream, w_oihw, U43, Cout, Cin, 0);
     VD_LAUNCH_CHECK("wino43_pack_kernel");
     return 0;
 }
 
-/* all tensors in one launch: items_dev = [n][8] int64 {w, U43, 0, Cout, Cin, 0, 0, first block}; a tensor takes (Cin/32)*(Cout/8) blocks */
+/* ---- FORWARD pass through F(4x4,3x3) (interpolation points {0, +-3/4, +-3/2, inf}; see the head of this file for the accuracy budget).
+ * Same geometries as the input gradient: 32x32 images, 64-wide images with H % 16 == 0, 16x16 images in multiples of four;
+ * Cin % 8 == 0 (GEMM K), Cout % 32 == 0, rows 16-byte aligned, tensors below 2 GiB. */
+extern "C" int vd_conv3x3_wino43_fwd_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t ldy,
+                                               int64_t ldres) {
+    if (nimg <= 0 || Cin % KT || Cout % TN || ldx % 4 || ldy % 4 || ldres % 4) return 0;
+    if (!((W == 32 && H == 32) || (W == 64 && H % 16 == 0 && H >= 16) || (W == 16 && H == 16 && nimg % 4 == 0))) return 0;
+    const long long px = (long long)nimg * H * W, lim = 0x7FFFFFF0LL / 4;
+    if (px * ldx >= lim || px * ldy >= lim || (ldres > 0 && px * ldres >= lim)) return 0;
+    return 1;
+}
+
+/* U43f = forward image of w[Cout][Cin][3][3]: (G w[co][ci] G^T)[36] in the kernel's lane order, vd_wino43_u_floats(Cout, Cin) floats */
+extern "C" int vd_wino43_pack_fwd(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43f, void* stream) {
+    VD_REQUIRE(w_oihw && U43f && Cin % KT == 0 && Cout % TN == 0, "vd_wino43_pack_fwd: needs Cin %% 8 == 0 and Cout %% 32 == 0");
+    hipLaunchKernelGGL(wino43_pack_kernel, dim3((unsigned)((Cout / TN) * (Cin / KT))), dim3(256), 0, (hipStream_t)stream, w_oihw, U43f, Cout, Cin, 1);
+    VD_LAUNCH_CHECK("wino43_pack_kernel(fwd)");
+    return 0;
+}
+
+/* y[nimg][H][W][:Cout] = conv3x3(x[nimg][H][W][:Cin], w) + bias (+ res), U43f = vd_wino43_pack_fwd(w); bias / res may be NULL.
+ * stats_part (or NULL): GroupNorm partial sums of y, [nimg][chunks][2][Cout] with one chunk per (image, work item): chunks =
+ * vd_conv3x3_wino43_fwd_chunk_rows gives the pixels per chunk (1024 for 32x32 and 64-wide images, 256 for 16x16 ones). */
+extern "C" int vd_conv3x3_wino43_fwd_chunk_rows(int32_t H, int32_t W) { return W == 16 ? H * W : (W == 32 ? H * W : 16 * W); }
+
+extern "C" int vd_conv3x3_wino43_fwd(const float* xin, int64_t ldx, const float* U43f, const float* bias, const float* res, int64_t ldres,
+                                     float* y, int64_t ldy, int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                     float* stats_part, void* stream) {
+    VD_REQUIRE(xin && U43f && y, "vd_conv3x3_wino43_fwd: null operand");
+    VD_REQUIRE(vd_conv3x3_wino43_fwd_supported(nimg, H, W, Cin, Cout, ldx, ldy, res ? ldres : 0),
+               "vd_conv3x3_wino43_fwd: unsupported geometry nimg=%d H=%d W=%d Cin=%d Cout=%d", nimg, H, W, Cin, Cout);
+    VD_REQUIRE(vd_aligned16(xin) && vd_aligned16(U43f) && vd_aligned16(y) && (!res || vd_aligned16(res)) && (!bias || vd_aligned16(bias)),
+               "vd_conv3x3_wino43_fwd: operands must be 16-byte aligned");
+    Args43 a = {};
+    a.x = xin; a.ldx = ldx; a.U = U43f; a.y = y; a.ldy = ldy;
+    a.nimg = nimg; a.H = H; a.W = W; a.K = Cin; a.N = Cout;
+    a.items_per_img = W == 64 ? H / 16 : 1;
+    a.ngrp = W == 16 ? nimg / 4 : nimg * a.items_per_img;
+    a.ncb = Cout / TN;
+    a.bias = bias; a.res = res; a.ldr = ldres; a.stats = stats_part; a.chunks_per_img = a.items_per_img;
+    const long long items = (long long)a.ngrp * a.ncb;
+    VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_wino43_fwd: too many work items");
+    a.nitems = (int)items;
+    const int ncu = vd_persistent_cus();
+    const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (W == 16) hipLaunchKernelGGL((wino43_conv_kernel<4, true>), grid, blk, 0, st, a);
+    else if (W == 32) hipLaunchKernelGGL((wino43_conv_kernel<8, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((wino43_conv_kernel<16, true>), grid, blk, 0, st, a);
+    VD_LAUNCH_CHECK("wino43_conv_kernel<., true>");
+    g_last43 = -(W / 4);
+    return 0;
+}
+
+/* all tensors in one launch: items_dev = [n][8] int64 {w, U43, fwd, Cout, Cin, 0, 0, first block}; fwd = 0: input-gradient image, (Cin/32)*(Cout/8)
+ * blocks; fwd = 1: forward image (vd_wino43_pack_fwd), (Cout/32)*(Cin/8) blocks */
 extern "C" int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream) {
     VD_REQUIRE(items_dev && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "vd_wino43_pack_batched: bad table");
     hipLaunchKernelGGL(wino43_pack_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,

@@ -57,6 +57,10 @@ _SIGNATURES = {
     "vd_wino43_u_floats": (_sz, [_i32, _i32]),
     "vd_conv3x3_dgrad_wino43": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vd_wino43_last_kernel": (C.c_int, []),
+    "vd_conv3x3_wino43_fwd_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64]),
+    "vd_wino43_pack_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "vd_conv3x3_wino43_fwd_chunk_rows": (C.c_int, [_i32, _i32]),
+    "vd_conv3x3_wino43_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vd_wino43_pack": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "vd_wino43_pack_batched": (C.c_int, [_vp, _i32, _i64, _vp]),
     "vd_conv3x3_wgrad_wino43_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64]),
@@ -342,13 +346,40 @@ def wino43_pack_batched(table, n, total_blocks):
     _check(lib().vd_wino43_pack_batched(table.data_ptr(), n, total_blocks, stream()), "vd_wino43_pack_batched")
 
 
+# forward convolutions of the 16x16 / 32x32 / 64-wide layers through F(4x4,3x3) with the dyadic interpolation points (csrc/wino43.hip:
+# 1.78x fewer matrix-core cycles than F(2x2,3x3), ~2x its output error, inside the stated 2e-5 bound); VD_WINO43_FWD=0 keeps F(2x2,3x3)
+WINO43_FWD = os.environ.get("VD_WINO43_FWD", "1") != "0"
+
+
+def wino43_fwd_supported(nimg, H, W, Cin, Cout, ldx, ldy, ldres=0):
+    return WINO and WINO43_FWD and bool(lib().vd_conv3x3_wino43_fwd_supported(nimg, H, W, Cin, Cout, ldx, ldy, ldres))
+
+
+def wino43_pack_fwd(w, Cout, Cin, U43f):
+    _check(lib().vd_wino43_pack_fwd(ptr(w), Cout, Cin, ptr(U43f), stream()), "vd_wino43_pack_fwd")
+
+
+def wino43_fwd_chunk_rows(H, W):
+    return int(lib().vd_conv3x3_wino43_fwd_chunk_rows(H, W))
+
+
+def conv3x3_wino43_fwd(x, ldx, U43f, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, stats_part=None):
+    """y = conv3x3(x, w) + bias (+ res) as Winograd F(4x4,3x3) (vd_conv3x3_wino43_fwd); `flops` recorded = the direct convolution's
+    (algorithmic) count, of which the matrix cores execute 1/4"""
+    name = f"wino43_conv_kernel<{W // 4}, true>"
+    with _TimedName(name, 2.0 * nimg * H * W * Cout * 9 * Cin):
+        _check(lib().vd_conv3x3_wino43_fwd(ptr(x), ldx, ptr(U43f), ptr(bias), ptr(res), ldres, ptr(y), ldy, nimg, H, W, Cin, Cout,
+                                           ptr(stats_part), stream()), "vd_conv3x3_wino43_fwd")
+    _note_bytes(name, 4.0 * (nimg * H * W * (Cin + Cout + (Cout if res is not None else 0)) + 36 * Cout * Cin))
+
+
 def conv3x3_dgrad_wino43(dy, lddy, U43, dx, lddx, nimg, H, W, Cin, Cout):
     """dx = input gradient of the Cin -> Cout 3x3 convolution (Winograd F(4x4,3x3), see vd_conv3x3_dgrad_wino43); `flops` recorded =
     the direct convolution's (algorithmic) count, of which the matrix cores execute 1/4"""
-    with _TimedName(f"wino43_dgrad_kernel<{W // 4}>", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    with _TimedName(f"wino43_conv_kernel<{W // 4}, false>", 2.0 * nimg * H * W * Cout * 9 * Cin):
         _check(lib().vd_conv3x3_dgrad_wino43(ptr(dy), lddy, ptr(U43), ptr(dx), lddx, nimg, H, W, Cin, Cout, stream()),
                "vd_conv3x3_dgrad_wino43")
-    _note_bytes(f"wino43_dgrad_kernel<{W // 4}>", 4.0 * (nimg * H * W * (Cin + Cout) + 36 * Cout * Cin))
+    _note_bytes(f"wino43_conv_kernel<{W // 4}, false>", 4.0 * (nimg * H * W * (Cin + Cout) + 36 * Cout * Cin))
 
 
 def conv3x3(x, ldx, wpack, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres=0, accumulate=False, stats_part=None):

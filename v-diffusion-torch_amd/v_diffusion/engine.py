@@ -157,9 +157,13 @@ class UNetEngine:
             return None                                   # tiny images: the norm computes its own statistics
         return torch.empty(H.stats_part_numel(nimg, HW, C), dtype=torch.float32, device=ref.device)
 
-    @staticmethod
-    def _parts(part, C, HW):
-        return None if part is None else [(part, C, HW // (H.last_row_tile() // 2))]
+    def _parts(self, part, C, HW):
+        """[(partials, channels, chunks per image)] of the launch that just wrote `part`: chunk = half the row tile of the tile engine /
+        64 rows of the F(2x2,3x3) kernels (both through vd_gemm_last_tile), or what the F(4x4,3x3) forward kernel says (_conv)"""
+        rows, self._last_chunk_rows = getattr(self, "_last_chunk_rows", None), None
+        if part is None:
+            return None
+        return [(part, C, HW // (rows or (H.last_row_tile() // 2)))]
 
     def _norm(self, x, x_parts, gn, film, act, p_drop, seed, rs, y, B, Hh, Ww, C):
         """y = resample(dropout(act(FiLM(GroupNorm(x))))); returns the [B][4][C] coefficient table the backward pass needs.
@@ -300,7 +304,7 @@ class UNetEngine:
         ``geom`` = (B, H0, W0) of the training input: the input gradients of the layers vd_conv3x3_dgrad_wino43 serves at that
         geometry take the F(4x4,3x3) image U43 instead of the rotated F(2x2,3x3) one."""
         ws = [c.weight for b in self.plan if b.res is not None for c in (b.res.conv1, b.res.conv2)]
-        key = (bool(need_d), H.WINO, geom if need_d else None) + tuple(w.data_ptr() for w in ws)
+        key = (bool(need_d), H.WINO, H.WINO43_FWD, geom) + tuple(w.data_ptr() for w in ws)
         if self._pack_state is None:
             self._pack_state = {}
         st = self._pack_state.pop(key, None)             # (re-inserted below as the most recent entry)
@@ -311,13 +315,17 @@ class UNetEngine:
             if H.WINO:
                 # Winograd-domain kernels U = G w G^T (csrc/wino.hip): [16][Cout][Cin] forward, [16][Cin][Cout] input gradient;
                 # csrc/wino43.hip: 36 x Cin x Cout in lane order for the input gradients it serves
-                use43 = {}
-                if need_d and geom is not None:
+                # per layer: which F(4x4,3x3) images the training / inference geometry lets it use (forward: u43f, input gradient: u43);
+                # a layer served by them gets no F(2x2,3x3) image for that direction (a call that declines packs one on demand: _conv)
+                use43, use43f = {}, {}
+                if geom is not None:
                     for (w, nb, lh, lw, ci, co) in self._conv_geoms(*geom):
-                        use43[id(w)] = H.wino43_supported(nb, lh, lw, ci, co, co, ci)
-                uf_all = torch.empty(16 * sum(sizes) // 9, dtype=torch.float32, device=dev)
+                        use43[id(w)] = need_d and H.wino43_supported(nb, lh, lw, ci, co, co, ci)
+                        use43f[id(w)] = H.wino43_fwd_supported(nb, lh, lw, ci, co, ci, co, co)
+                nf = sum(n for w, n in zip(ws, sizes) if not use43f.get(id(w)))
                 nd = sum(n for w, n in zip(ws, sizes) if not use43.get(id(w))) if need_d else 0
-                n43 = sum(n for w, n in zip(ws, sizes) if use43.get(id(w)))
+                n43 = sum(n for w, n in zip(ws, sizes) if use43.get(id(w))) + sum(n for w, n in zip(ws, sizes) if use43f.get(id(w)))
+                uf_all = torch.empty(16 * nf // 9, dtype=torch.float32, device=dev) if nf else None
                 ud_all = torch.empty(16 * nd // 9, dtype=torch.float32, device=dev) if nd else None
                 u43_all = torch.empty(36 * n43 // 9, dtype=torch.float32, device=dev) if n43 else None
                 wrows, wviews, woff, doff, wblk = [], {}, 0, 0, 0
@@ -325,8 +333,15 @@ class UNetEngine:
                 for w, n in zip(ws, sizes):
                     co, ci = w.shape[0], w.shape[1]
                     m = 16 * co * ci
-                    uf = uf_all[woff: woff + m].view(16, co, ci)
-                    ud = u43 = None
+                    uf = ud = u43 = u43f = None
+                    if use43f.get(id(w)):
+                        u43f = u43_all[off43: off43 + 36 * co * ci]
+                        rows43.append([w.data_ptr(), u43f.data_ptr(), 1, co, ci, 0, 0, blk43])
+                        off43 += 36 * co * ci
+                        blk43 += (co // 32) * (ci // 8)
+                    else:
+                        uf = uf_all[woff: woff + m].view(16, co, ci)
+                        woff += m
                     if need_d and use43.get(id(w)):
                         u43 = u43_all[off43: off43 + 36 * co * ci]
                         rows43.append([w.data_ptr(), u43.data_ptr(), 0, co, ci, 0, 0, blk43])
@@ -335,12 +350,15 @@ class UNetEngine:
                     elif need_d:
                         ud = ud_all[doff: doff + m].view(16, ci, co)
                         doff += m
+                    wviews[id(w)] = (uf, ud, u43, u43f)
+                    if uf is None and ud is None:
+                        continue
                     tiled = int(co % 16 == 0 and ci % 16 == 0)
-                    wrows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr() if ud is not None else 0, co, ci, tiled, 0, wblk])
-                    wviews[id(w)] = (uf, ud, u43)
-                    woff += m
+                    wrows.append([w.data_ptr(), uf.data_ptr() if uf is not None else 0, ud.data_ptr() if ud is not None else 0, co, ci,
+                                  tiled, 0, wblk])
                     wblk += (co // 16) * (ci // 16) if tiled else (co * ci + 255) // 256
-                st.update(uf=uf_all, ud=ud_all, u43=u43_all, wtable=torch.tensor(wrows, dtype=torch.int64).to(dev), wblocks=wblk,
+                st.update(uf=uf_all, ud=ud_all, u43=u43_all, wtable=torch.tensor(wrows, dtype=torch.int64).to(dev) if wrows else None,
+                          nw=len(wrows), wblocks=wblk,
                           wviews=wviews, table43=torch.tensor(rows43, dtype=torch.int64).to(dev) if rows43 else None,
                           n43=len(rows43), blocks43=blk43)
             else:
@@ -363,7 +381,8 @@ class UNetEngine:
         if H.WINO:
             # every convolution the Winograd kernels serve needs only U; the direct packs are made per tensor, on demand, by
             # _pack_f / _pack_d for the geometries that fall back (none in the shipped configs)
-            H.wino_pack_batched(st["wtable"], st["n"], st["wblocks"])
+            if st["nw"]:
+                H.wino_pack_batched(st["wtable"], st["nw"], st["wblocks"])
             if st["n43"]:
                 H.wino43_pack_batched(st["table43"], st["n43"], st["blocks43"])
             self._wino = st["wviews"]
@@ -376,6 +395,14 @@ class UNetEngine:
         """3x3 convolution with kernel ``w`` (forward) or its input gradient (``dgrad``: x = dy, Cin/Cout are the GEMM's):
         Winograd F(2x2,3x3) wherever the geometry is served, the direct implicit GEMM otherwise."""
         wino = getattr(self, "_wino", None)
+        self._last_chunk_rows = None
+        if wino is not None and not dgrad and id(w) in wino and wino[id(w)][3] is not None \
+                and H.wino43_fwd_supported(B, Hh, Ww, Cin, Cout, ldx, ldy, ldres if res is not None else 0):
+            # forward pass through F(4x4,3x3) (csrc/wino43.hip, dyadic interpolation points); its GroupNorm partials come one chunk per
+            # (image, work item)
+            H.conv3x3_wino43_fwd(x, ldx, wino[id(w)][3], bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres, stats_part=stats_part)
+            self._last_chunk_rows = H.wino43_fwd_chunk_rows(Hh, Ww)
+            return
         if wino is not None and dgrad and id(w) in wino and wino[id(w)][2] is not None \
                 and H.wino43_supported(B, Hh, Ww, Cout, Cin, ldx, ldy):
             # F(4x4,3x3) input gradient (csrc/wino43.hip): x = dy [.., Cin = conv Cout], y = dx [.., Cout = conv Cin].  The pack-time choice
@@ -390,6 +417,10 @@ class UNetEngine:
                 # a layer packed for the F(4x4,3x3) input gradient whose call declined it: rotated F(2x2,3x3) image on demand
                 U = torch.empty(16, w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
                 H.wino_pack(w, w.shape[0], w.shape[1], ud=U)
+            elif U is None:
+                # ... and likewise the forward image of a layer packed for the F(4x4,3x3) forward pass
+                U = torch.empty(16, w.shape[0], w.shape[1], dtype=torch.float32, device=w.device)
+                H.wino_pack(w, w.shape[0], w.shape[1], uf=U)
             if U is not None:
                 H.conv3x3_wino(x, ldx, U, bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres, stats_part=stats_part)
                 return
