@@ -54,6 +54,26 @@ for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256)
     e2, e4 = (dx2.double() - ref).abs().max().item(), (dx4.double() - ref).abs().max().item()
     r2, r4 = ((dx2.double() - ref).norm() / ref.norm()).item(), ((dx4.double() - ref).norm() / ref.norm()).item()
     fl = 2.0 * nimg * Hh * Ww * Cout * 9 * Cin
+    # forward pass (round 4): F(2x2,3x3) with GroupNorm partials + bias + residual against the F(4x4,3x3) forward kernel, same operands
+    x = torch.nn.functional.silu(torch.randn((nimg, Hh, Ww, Cin), device=DEV, generator=g))
+    bias = torch.randn((Cout,), device=DEV, generator=g)
+    res = torch.randn((nimg, Hh, Ww, Cout), device=DEV, generator=g)
+    uf = torch.empty(16, Cout, Cin, device=DEV)
+    H.wino_pack(w, Cout, Cin, uf=uf)
+    u43f = torch.empty(H.lib().vd_wino43_u_floats(Cout, Cin), device=DEV)
+    H.wino43_pack_fwd(w, Cout, Cin, u43f)
+    y2, y4 = torch.empty(nimg, Hh, Ww, Cout, device=DEV), torch.empty(nimg, Hh, Ww, Cout, device=DEV)
+    part = torch.empty(H.stats_part_numel(nimg, Hh * Ww, Cout), device=DEV)
+    g2 = lambda: H.conv3x3_wino(x, Cin, uf, bias, y2, Cout, nimg, Hh, Ww, Cin, Cout, res=res, ldres=Cout, stats_part=part)
+    g4 = lambda: H.conv3x3_wino43_fwd(x, Cin, u43f, bias, y4, Cout, nimg, Hh, Ww, Cin, Cout, res=res, ldres=Cout, stats_part=part)
+    g4n = lambda: H.conv3x3_wino43_fwd(x, Cin, u43f, bias, y4, Cout, nimg, Hh, Ww, Cin, Cout, stats_part=part)
+    tf2, tf4, tf4n = timeit(g2), timeit(g4), timeit(g4n)
+    reff = conv_fp64(x, w) + bias.double() + res.double()
+    ef2, ef4 = (y2.double() - reff).abs().max().item(), 0.0
+    g4(); torch.cuda.synchronize()
+    ef4 = (y4.double() - reff).abs().max().item()
+    print(f"{nimg}x{Hh}x{Ww} {Cin}->{Cout} FORWARD: F(2,3) {tf2:.3f} ms err {ef2:.2e} | F(4,3) fwd {tf4:.3f} ms ({fl / 4 / tf4 / 1e9:.0f} exe) err {ef4:.2e}, "
+          f"without residual {tf4n:.3f} ms | input gradient {t4:.3f} ms | x{tf2 / tf4:.2f}")
     print(f"{nimg}x{Hh}x{Ww} {Cout}->{Cin}: F(2,3) {t2:.3f} ms ({fl / t2 / 1e9:.0f} alg TF) err {e2:.2e} rel-L2 {r2:.2e} | "
           f"F(4,3) {t4:.3f} ms ({fl / t4 / 1e9:.0f} alg TF, {fl / 4 / t4 / 1e9:.0f} exe) err {e4:.2e} rel-L2 {r4:.2e} | scale {sc:.1f} | x{t2 / t4:.2f}")
 

@@ -61,6 +61,10 @@ struct Args43 {
     int chunks_per_img;                       // 1 (32x32, 16x16) or H/16 (64 wide)
 };
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load / store of the wave
+// (vmcnt(0)), which in the epilogue would expose the latency of the residual loads and the drain of the output stores at each barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, int records = (int)OOB) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
 }
@@ -85,6 +89,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #ifndef VD_W43_SB
 #define VD_W43_SB 12          /* MFMA step (of 18 per K tile) the tile barrier sits in front of */
 #endif
+#ifndef VD_W43_UPF
+#define VD_W43_UPF 2          /* MFMA steps a U fragment is read ahead of its use (same-box A/B of 1 / 2 / 3, tests/probe/r04_pass7.sh: 2 and 3 are ~1 % ahead of 1) */
+#endif
 #ifndef VD_W43_DPS
 #define VD_W43_DPS 1          /* DMA pieces of tile kt+2 issued per step behind the barrier */
 #endif
@@ -92,15 +99,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 template <int HALF, bool DY, typename T>
 __device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
     if (DY) {
+        // rows 1, 2 = (d4 - 9/4 d2) +- 3/4 (d3 - 9/4 d1), rows 3, 4 = (d4 - 9/16 d2) +- 3/2 (d3 - 9/16 d1): as many instructions as the classic set
         if (HALF == 0) {
-            const T e1 = d[4] - 2.25f * d[2], f1 = 0.75f * d[3] - 1.6875f * d[1];
+            const T e1 = d[4] - 2.25f * d[2], f1 = d[3] - 2.25f * d[1];
             o0 = 1.265625f * d[0] + (d[4] - 2.8125f * d[2]);
-            o1 = e1 + f1;
-            o2 = e1 - f1;
+            o1 = e1 + 0.75f * f1;
+            o2 = e1 - 0.75f * f1;
         } else {
-            const T e2 = d[4] - 0.5625f * d[2], f2 = 1.5f * d[3] - 0.84375f * d[1];
-            o0 = e2 + f2;
-            o1 = e2 - f2;
+            const T e2 = d[4] - 0.5625f * d[2], f2 = d[3] - 0.5625f * d[1];
+            o0 = e2 + 1.5f * f2;
+            o1 = e2 - 1.5f * f2;
             o2 = 1.265625f * d[1] + (d[5] - 2.8125f * d[3]);
         }
     } else if (HALF == 0) {
@@ -119,13 +127,13 @@ __device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
 template <bool DY, typename T>
 __device__ __forceinline__ void bt_full(const T (&r)[6], T (&v)[6]) {
     if (DY) {
-        const T e1 = r[4] - 2.25f * r[2], f1 = 0.75f * r[3] - 1.6875f * r[1];
-        const T e2 = r[4] - 0.5625f * r[2], f2 = 1.5f * r[3] - 0.84375f * r[1];
+        const T e1 = r[4] - 2.25f * r[2], f1 = r[3] - 2.25f * r[1];
+        const T e2 = r[4] - 0.5625f * r[2], f2 = r[3] - 0.5625f * r[1];
         v[0] = 1.265625f * r[0] + (r[4] - 2.8125f * r[2]);
-        v[1] = e1 + f1;
-        v[2] = e1 - f1;
-        v[3] = e2 + f2;
-        v[4] = e2 - f2;
+        v[1] = e1 + 0.75f * f1;
+        v[2] = e1 - 0.75f * f1;
+        v[3] = e2 + 1.5f * f2;
+        v[4] = e2 - 1.5f * f2;
         v[5] = 1.265625f * r[1] + (r[5] - 2.8125f * r[3]);
         return;
     }
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
     // the tile barrier sits in front of MFMA step SB of 18; the NAFTER steps behind it carry the row pass of the next tile and DPS DMA
     // pieces each of the tile after that
     constexpr int SB = VD_W43_SB, NAFTER = 18 - SB, DPS = VD_W43_DPS, PAFTER = NAFTER * DPS;
+    constexpr int UPF = VD_W43_UPF;
     static_assert(PAFTER <= NPIECE && NPIECE - PAFTER <= SB, "DMA schedule does not fit the tile");
 
     // ---- LDS read addresses (floats): patch position (pr, q) of this lane's tile, channels {2 lq, 2 lq + 1}
@@ -331,8 +340,10 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                 const float* san = smem + (st ^ 1) * STAGE + pbase;
                 const bool n1 = kt + 1 < nkt, n2 = kt + 2 < nkt;
                 f32x2 Rn[3][6];
-                f32x4 uf[2], ufl[NAFTER];
-                uf[0] = *reinterpret_cast<const f32x4*>(su + (18 * HALF) * 256);
+                // U fragments: read UPF steps ahead of their MFMAs (ring of UPF + 1), those of steps SB..17 in front of the barrier
+                f32x4 uf[UPF + 1], ufl[NAFTER];
+#pragma unroll
+                for (int e = 0; e < UPF; ++e) uf[e] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + e) * 256);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     f32x2 V[6];
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             if (VD_W43_EXP != 5) __syncthreads();
                         }
-                        if (xl < SB - 1 && VD_W43_EXP != 4) uf[(xl + 1) & 1] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + 1) * 256);
+                        if (xl + UPF < SB && VD_W43_EXP != 4) uf[(xl + UPF) % (UPF + 1)] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + UPF) * 256);
                         // DMA of tile kt+1: pieces PAFTER .. NPIECE-1 in the first steps of this tile (pieces 0 .. PAFTER-1 went out behind
                         // the barrier of tile kt-1); DMA of tile kt+2: pieces 0 .. PAFTER-1 behind this tile's barrier
                         if (xl + PAFTER < NPIECE && !(VD_W43_EXP >= 1 && VD_W43_EXP <= 4)) { if (n1) issue_piece(xl + PAFTER, kt + 1, st ^ 1, cb); }
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                             }
                             rowpass(san, Rn, (6 * (xl - SB)) / NAFTER, (6 * (xl - SB + 1)) / NAFTER);     // (last tile: a stale stage, result unused)
                         }
-                        const f32x4 u = xl < SB ? uf[xl & 1] : ufl[xl < SB ? 0 : xl - SB];
+                        const f32x4 u = xl < SB ? uf[xl % (UPF + 1)] : ufl[xl < SB ? 0 : xl - SB];
                         acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0], V[b][0], acc[xl][0], 0, 0, 0);
                         acc[xl][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2], V[b][0], acc[xl][1], 0, 0, 0);
                         acc[xl][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1], V[b][1], acc[xl][0], 0, 0, 0);
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
             const int li_e = lane_e & 15, lq_e = lane_e >> 4;
             const int tl_e = 16 * tg + li_e, tyl_e = tl_e >> LGT, tx_e = tl_e & (TWT - 1);
             f32x4 Y[4][4];
+            f32x4 RV[FWD ? 4 : 1][FWD ? 4 : 1];                    // forward: the residual of this wave's output block
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int blk = pass == 0 ? 1 - HALF : HALF;        // first the block that is given away
@@ -423,7 +435,25 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) xch[(wave * 16 + 4 * u + v) * 64 + lane_e] = Y[u][v];
-                    __syncthreads();
+                    if (FWD) {
+                        // the residual of the block this wave finishes: all 16 loads go out here, behind the exchange stores, so that their
+                        // latency runs under the barrier and the second transform pass (the accumulators of the block given away are dead)
+                        const int img_r = QUAD ? 4 * grp + (tyl_e >> 2) : grp / p.items_per_img;
+                        const int part_r = QUAD ? 0 : grp - img_r * p.items_per_img;
+                        const int y0r = QUAD ? 4 * (tyl_e & 3) : 4 * (NTR * part_r + tyl_e);
+                        const unsigned pixr = (unsigned)((img_r * p.H + y0r) * p.W + 4 * tx_e);
+                        const unsigned n0r = (unsigned)(cb * TN + 16 * HALF + 4 * lq_e);
+                        const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                RV[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                if (p.res) RV[u][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rrs, (int)(((pixr + (unsigned)(u * p.W + v)) * (unsigned)p.ldr + n0r) * 4u), 0, 0));
+                            }
+                    }
+                    lds_barrier();                                  // (the residual loads stay in flight across it)
                 }
             }
             {
@@ -443,29 +473,19 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                 const unsigned ldy_u = (unsigned)p.ldy;
                 const unsigned pix00 = (unsigned)((img * p.H + y0) * p.W + x0);
                 if (FWD) {
-                    // + bias (+ residual: the skip path of the residual block, fetched a tile row at a time), then the GroupNorm partial
+                    // + bias (+ residual: the skip path of the residual block, fetched in front of the exchange barrier), then the GroupNorm partial
                     // sums of what is written: per lane over its 16 pixels, over the 16 tiles of the wave by shuffles
                     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                     if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0);
-                    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
-                    const unsigned ldr_u = (unsigned)p.ldr;
                     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        f32x4 rv[4];
+                    for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            rv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (p.res) rv[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   rrs, (int)(((pix00 + (unsigned)(u * p.W + v)) * ldr_u + (unsigned)n0) * 4u), 0, 0));
-                        }
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const f32x4 val = (Y[u][v] + bv) + rv[v];
+                            const f32x4 val = (Y[u][v] + bv) + RV[FWD ? u : 0][FWD ? v : 0];
                             Y[u][v] = val;
                             s1 += val; s2 += val * val;
                         }
-                    }
                     if (p.stats) {
 #pragma unroll
                         for (int o = 1; o < 16; o <<= 1) {
@@ -490,7 +510,8 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                         __builtin_amdgcn_raw_buffer_store_b128(wv, yrs, (int)vo, 0, 0);
                     }
             }
-            __syncthreads();                                        // the exchange area is read: the next item's DMA may overwrite it
+            lds_barrier();                                          // the exchange area is read: the next item's DMA may overwrite it (the output
+                                                                    // stores drain behind the barrier, under the next item's first-stage DMA)
             if (FWD && p.stats) {
                 // partial sums of the item: one chunk per image it holds -- the four tile-group waves of a xi half together (one 32x32
                 // image, 16 rows of a 64-wide one) or one wave each (QUAD: a wave's 16 tiles are one 16x16 image).  Fixed order, no atomics.
