@@ -118,10 +118,9 @@ def cpu_baseline(wl="cifar10", batch=16, budget_s=18.0):
                       f"torch CPU fp32 on {ncpu} threads, {model_name}"}
 
 
-# fwd_exec_frac: share of the ALGORITHMIC forward FLOPs the matrix cores execute.  The residual-block 3x3 convolutions run as
-# Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and channel pair where the convolution defines 36): conv3x3 FLOPs of
-# SURVEY 8 minus the thin in/out convolutions, x 4/9, plus everything else at 1.  CIFAR: (32.61 * 4/9 + 0.03 + 5.00) / 37.64;
-# CelebA: (183.71 * 4/9 + 0.09 + 17.50) / 201.3
+# fwd_exec_frac: share of the ALGORITHMIC forward FLOPs the matrix cores execute -- FALLBACK ONLY (non-zero ranks, which record no launches):
+# the sampling roofline takes the share from the launches two reverse steps of the run record (sample_once).  These constants are the
+# all-F(2x2,3x3) values: CIFAR (32.61 * 4/9 + 0.03 + 5.00) / 37.64; CelebA (183.71 * 4/9 + 0.09 + 17.50) / 201.3
 WORKLOADS = {
     "cifar10": dict(cfg=CIFAR, res=32, fwd_gflop=FWD_GFLOP_PER_IMG, fwd_exec_frac=0.5187, short="CIFAR-10 cond UNet",
                     name="CIFAR-10 32x32 class-cond v-pred UNet (cifar10_cond.json, 60.8M params)"),
@@ -295,7 +294,9 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
         dom = max(agg, key=lambda k: agg[k][1])
         fl, tt_, n = agg[dom]
         tname, tj = traffic_table(wl)
-        key = dom.split(" (+")[0]
+        # (the 36 xi planes of the F(4x4,3x3) weight gradient run as this instantiation of the grouped tile engine: its rocprof name)
+        key = {"wino43_wgrad_gemm (gemm_dma_kernel<..., grouped> x 36 planes)": "gemm_dma_kernel<128, 128, 1, 1, true, 16, true, true>"}.get(
+            dom, dom.split(" (+")[0])
         traffic = tj[key]["hbm_bytes_per_launch"] if key in tj else None
         ab = _hip.PROFILE_BYTES.get(dom)
         alg_bytes = ab[0] / ab[1] if ab else None
@@ -315,14 +316,14 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
                     "executed_share_of_algorithmic_flops": round(exe, 4),
                     "algorithmic_bytes_per_launch": None if alg_bytes is None else round(alg_bytes),
                     "traffic_ratio": None if (alg_bytes is None or traffic is None) else round(traffic / alg_bytes, 3),
-                    "note": ("Winograd F(2x2,3x3): the kernel executes 4/9 of the direct convolution's FLOPs on the matrix cores (exact "
-                             "fp32); achieved/frac count executed FLOPs, algorithmic_tflops the direct convolution's") if exe < 1 else None,
+                    "note": (f"Winograd kernel: the matrix cores execute {exe:.4f} of the direct convolution's FLOPs (F(2x2,3x3): 4/9, F(4x4,3x3): 1/4; "
+                             "exact fp32 products); achieved / frac count executed FLOPs, algorithmic_tflops / frac_vs_direct_roofline the "
+                             "direct convolution's 2*M*N*K (SURVEY 8d)") if exe < 1 else None,
                     "traffic_note": (f"HBM+fabric bytes per launch of this kernel in the same bench command, PMC passes (FETCH_SIZE, WRITE_SIZE: "
                                      f"they cannot run inside the timed region) tracked as profiles/{tname}; traffic_ratio = traffic / "
                                      f"algorithmic bytes (x + y + residual + U read / written once)") if tname else None,
-                    "clock_note": ("peak = 2.4 GHz figure; in-kernel s_memtime/s_memrealtime stamps show the shader clock at 1.75-1.9 GHz while the "
-                                   "Winograd convolution runs and 2.1 GHz under its weight gradient (DESIGN.md section 3, profiles/r03_wino_clock.txt)")
-                                  if exe < 1 else None,
+                    "clock_note": ("peak = 2.4 GHz figure; PMC passes (profiles/r04_wino_pmc.json) put the shader clock at 2.15-2.2 GHz under the "
+                                   "Winograd kernels and the grouped weight-gradient GEMMs (DESIGN.md section 3)") if exe < 1 else None,
                     "launches_per_step": n // 2, "avg_launch_ms": round(tt_ / n * 1e3, 4),
                     "flops_per_launch": round(exe * fl / n / 1e9, 3), "flops_unit": "GFLOP executed on the matrix cores per launch",
                     "algorithmic_flops_per_launch": round(fl / n / 1e9, 3),
