@@ -420,6 +420,7 @@ def main():
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: the gloo side channel (a host flag per update) needs no hostname lookup
         backend = os.environ.get("VD_BENCH_BACKEND", "nccl")                                  # "nccl" == RCCL on ROCm
         opts = None
         if backend == "nccl" and os.environ.get("VD_RCCL_HIGH_PRIORITY", "0") != "0":

@@ -989,6 +989,48 @@ def test_conv3x3_wino43_fwd(H, case):
           name="wino43 forward (plain)")
 
 
+def test_wino43_tensors_beyond_2gib(H):
+    """The 32x32 / 64-wide geometries address one image with 32-bit offsets and carry the image's 64-bit offset in the buffer descriptor,
+    so x / y / residual / dy / dx may exceed 2 GiB (CelebA sampling at 512 rows: [512, 64, 64, 576] is 4.8 GB).  136 images of 64x64x1024
+    = 2.28 GB on the wide side; first, middle and last image against fp64."""
+    nimg, Hh, Ww, Cw, Cn = 136, 64, 64, 1024, 32
+    assert nimg * Hh * Ww * Cw * 4 > 2 ** 31
+    g = torch.Generator(DEV).manual_seed(5)
+    big = torch.randn((nimg, Hh, Ww, Cw), device=DEV, generator=g)
+    w = torch.randn((Cn, Cw, 3, 3), device=DEV, generator=g) * (9 * Cw) ** -0.5
+    pick = (0, nimg // 2, nimg - 1)
+
+    def conv64(xs, wt):
+        xp = F.pad(xs.double(), (0, 0, 1, 1, 1, 1))
+        out = torch.zeros(xs.shape[0], Hh, Ww, wt.shape[0], dtype=torch.float64, device=DEV)
+        for ky in range(3):
+            for kx in range(3):
+                out += xp[:, ky:ky + Hh, kx:kx + Ww, :] @ wt[:, :, ky, kx].double().T
+        return out
+    # forward: x beyond 2 GiB (Cin = 1024 -> Cout = 32), residual + statistics on
+    assert H.lib().vd_conv3x3_wino43_fwd_supported(nimg, Hh, Ww, Cw, Cn, Cw, Cn, Cn) == 1
+    u43f = torch.empty(H.lib().vd_wino43_u_floats(Cn, Cw), device=DEV)
+    H.wino43_pack_fwd(w, Cn, Cw, u43f)
+    res = torch.randn((nimg, Hh, Ww, Cn), device=DEV, generator=g)
+    y = torch.empty(nimg, Hh, Ww, Cn, device=DEV)
+    H.conv3x3_wino43_fwd(big, Cw, u43f, None, y, Cn, nimg, Hh, Ww, Cw, Cn, res=res, ldres=Cn)
+    for i in pick:
+        ref = conv64(big[i:i + 1], w) + res[i:i + 1].double()
+        err = (y[i:i + 1].double() - ref).abs().max().item()
+        assert err <= 1.5e-5 * max(ref.abs().max().item(), 1.0), f"forward, image {i}: {err:.3e}"
+    # input gradient: dx beyond 2 GiB (conv Cin = 1024, Cout = 32: dy has 32 channels)
+    assert H.lib().vd_conv3x3_dgrad_wino43_supported(nimg, Hh, Ww, Cw, Cn, Cn, Cw) == 1
+    u43 = torch.empty(H.lib().vd_wino43_u_floats(Cn, Cw), device=DEV)
+    H.wino43_pack(w, Cn, Cw, u43)
+    dy = torch.randn((nimg, Hh, Ww, Cn), device=DEV, generator=g)
+    H.conv3x3_dgrad_wino43(dy, Cn, u43, big, Cw, nimg, Hh, Ww, Cw, Cn)            # (dx overwrites the big buffer)
+    wrot = w.flip(2, 3).transpose(0, 1).contiguous()
+    for i in pick:
+        ref = conv64(dy[i:i + 1], wrot)
+        err = (big[i:i + 1].double() - ref).abs().max().item()
+        assert err <= 6e-5 * max(ref.abs().max().item(), 1.0), f"input gradient, image {i}: {err:.3e}"
+
+
 def test_conv3x3_dgrad_wino43_rejects_unsupported(H):
     f = H.lib().vd_conv3x3_dgrad_wino43_supported
     assert f(2, 16, 16, 32, 32, 32, 32) == 0             # 16x16 images are served four at a time

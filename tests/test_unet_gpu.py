@@ -127,6 +127,20 @@ def test_full_size_unet_vs_golden(vd, golden_dir, name, cfgname, B, R, label):
         assert torch.equal(out2, out.detach())
 
 
+def test_full_size_unet_with_f23_forward_in_subprocess():
+    """the same full-size comparison with VD_WINO43_FWD=0 (read once per process): every residual-block convolution's forward pass on
+    the F(2x2,3x3) kernels, which the shipped choice leaves to the 8x8 level -- the A/B switch must stay inside the same bound"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-s", "--no-header", "-p", "no:cacheprovider",
+                        "-k", "test_full_size_unet_vs_golden"], env=dict(os.environ, VD_WINO43_FWD="0"), capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    print("\n".join(l for l in r.stdout.splitlines() if "out err" in l))
+
+
 def test_shard_gradients_sum_to_full_batch(vd):
     """data parallel invariant (SURVEY 4 iv): sum over shards of sum-loss gradients == full-batch gradient"""
     from oracle.cases import TINY, make_inputs

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
     unsigned pxo[APL];
     const float* xitem = p.x;                                       // QUAD: first image of the item (the lane offsets pxo are item-invariant)
     auto offsets = [&](int grp) {                                   // tile group = (image, part of the image) / QUAD: four images
-        int img = grp / p.items_per_img;
+        const int img = grp / p.items_per_img;
         const int part = grp - img * p.items_per_img;
         const int y_first = 4 * NTR * part - 1;
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                 if (i4 >= 4) yy = -1;                               // (offsets relative to the item's first image: xitem below)
             } else {
                 c = cs / RUN; idx = cs - c * RUN;
-                im = img; yy = y_first + r;
+                im = 0; yy = y_first + r;                           // (relative to the item's image: xitem carries the 64-bit part, so tensors beyond 2 GiB are fine)
             }
             const int xx = 4 * idx + c - 1;
             unsigned vo = OOB;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
         if (QUAD) offsets(0);
         for (int n = 0; item_of(n, cb, grp); ++n) {
             if (QUAD) xitem = p.x + (long long)grp * (4 * 16 * 16) * p.ldx;
-            else offsets(grp);
+            else { offsets(grp); xitem = p.x + (long long)(grp / p.items_per_img) * p.H * p.W * p.ldx; }
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) issue_piece(i, 0, 0, cb);
             f32x4 acc[18][2];
@@ -441,9 +441,11 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                         const int img_r = QUAD ? 4 * grp + (tyl_e >> 2) : grp / p.items_per_img;
                         const int part_r = QUAD ? 0 : grp - img_r * p.items_per_img;
                         const int y0r = QUAD ? 4 * (tyl_e & 3) : 4 * (NTR * part_r + tyl_e);
-                        const unsigned pixr = (unsigned)((img_r * p.H + y0r) * p.W + 4 * tx_e);
+                        // (non-QUAD: the image is uniform over the workgroup, so its 64-bit offset goes into the descriptor base)
+                        const unsigned pixr = (unsigned)(((QUAD ? img_r : 0) * p.H + y0r) * p.W + 4 * tx_e);
                         const unsigned n0r = (unsigned)(cb * TN + 16 * HALF + 4 * lq_e);
-                        const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.res ? p.res : p.y, p.res ? (int)OOB : 0);
+                        const float* rbase = p.res ? p.res + (QUAD ? 0LL : (long long)img_r * p.H * p.W * p.ldr) : p.y;
+                        const __amdgpu_buffer_rsrc_t rrs = make_rsrc(rbase, p.res ? (int)OOB : 0);
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -469,9 +471,9 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                 const int part = QUAD ? 0 : grp - img * p.items_per_img;
                 const int n0 = cb * TN + 16 * HALF + 4 * lq_e;
                 const int y0 = QUAD ? 4 * (tyl_e & 3) : 4 * (NTR * part + tyl_e), x0 = 4 * tx_e;
-                const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y);
+                const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y + (QUAD ? 0LL : (long long)img * p.H * p.W * p.ldy));
                 const unsigned ldy_u = (unsigned)p.ldy;
-                const unsigned pix00 = (unsigned)((img * p.H + y0) * p.W + x0);
+                const unsigned pix00 = (unsigned)(((QUAD ? img : 0) * p.H + y0) * p.W + x0);
                 if (FWD) {
                     // + bias (+ residual: the skip path of the residual block, fetched in front of the exchange barrier), then the GroupNorm partial
                     // sums of what is written: per lane over its 16 pixels, over the 16 tiles of the wave by shuffles
@@ -770,7 +772,9 @@ thread_local int g_last43w = 0;        // split-K slabs of the calling thread's 
 extern "C" int vd_conv3x3_dgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t lddy, int64_t lddx) {
     if (nimg <= 0 || Cout % KT || Cin % TN || lddy % 4 || lddx % 4) return 0;
     if (!((W == 32 && H == 32) || (W == 64 && H % 16 == 0 && H >= 16) || (W == 16 && H == 16 && nimg % 4 == 0))) return 0;
-    const long long px = (long long)nimg * H * W, lim = 0x7FFFFFF0LL / 4;
+    // 32-bit byte offsets: inside ONE image for the 32x32 / 64-wide geometries (the image's 64-bit offset sits in the buffer
+    // descriptor), inside the whole tensor for the 16x16 one (a work item spans four images, lanes address different ones)
+    const long long px = (W == 16 ? (long long)nimg : 1LL) * H * W, lim = 0x7FFFFFF0LL / 4;
     if (px * lddy >= lim || px * lddx >= lim) return 0;
     return 1;
 }
@@ -823,7 +827,7 @@ extern "C" int vd_conv3x3_wino43_fwd_supported(int32_t nimg, int32_t H, int32_t 
                                                int64_t ldres) {
     if (nimg <= 0 || Cin % KT || Cout % TN || ldx % 4 || ldy % 4 || ldres % 4) return 0;
     if (!((W == 32 && H == 32) || (W == 64 && H % 16 == 0 && H >= 16) || (W == 16 && H == 16 && nimg % 4 == 0))) return 0;
-    const long long px = (long long)nimg * H * W, lim = 0x7FFFFFF0LL / 4;
+    const long long px = (W == 16 ? (long long)nimg : 1LL) * H * W, lim = 0x7FFFFFF0LL / 4;        // (see the input gradient's _supported)
     if (px * ldx >= lim || px * ldy >= lim || (ldres > 0 && px * ldres >= lim)) return 0;
     return 1;
 }

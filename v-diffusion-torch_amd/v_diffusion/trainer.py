@@ -265,7 +265,12 @@ class HotPathTrainer:
                 # averaged over ranks; a rank-local decision would let replicas that saw y = None skip an update the others apply).  The
                 # flag travels as a host integer over a gloo group: no device synchronisation on the step's critical path.
                 ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-                self._flag_group = dist.new_group(ranks=ranks, backend="gloo")
+                try:
+                    self._flag_group = dist.new_group(ranks=ranks, backend="gloo")
+                except Exception as e:       # no usable gloo transport on this node: the flag travels through the gradient group instead
+                    import warnings
+                    warnings.warn(f"gloo flag group unavailable ({e}); the class-embedding flag is reduced on the device (one host sync per update)")
+                    self._flag_group = "device"
 
     def draw(self, x):
         B = x.shape[0]
@@ -312,7 +317,11 @@ class HotPathTrainer:
                 # reference semantics of parameters without a gradient (torch.optim.AdamW skips them: no moment decay, no weight
                 # decay, no update, their own step counter): see vd_adamw_ema
                 cls_grad = bool(getattr(self, "_cls_grad", False))
-                if self._flag_group is not None:                   # any rank had labels -> every rank applies the averaged gradient
+                if self._flag_group == "device":
+                    f = torch.tensor([int(cls_grad)], dtype=torch.int32, device=self.device)
+                    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.reducer.group)
+                    cls_grad = bool(f.item())
+                elif self._flag_group is not None:                 # any rank had labels -> every rank applies the averaged gradient
                     f = torch.tensor([int(cls_grad)], dtype=torch.int32)
                     dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self._flag_group)
                     cls_grad = bool(f.item())
