@@ -79,7 +79,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #endif
 // timing experiments (WRONG results; built only by tests/probe/w43_exp.sh into scratch libraries, never into the product or the
 // probe library): 1 = no DMA inside the K loop, 2 = also no transform arithmetic, 3 = also no patch reads, 4 = also no U-fragment
-// reads, 5 = full kernel without the tile barrier
+// reads, 5 = full kernel without the tile barrier, 6 = full kernel that does not wait for an item's first stage (upper bound of a cross-item prefetch)
 #ifndef VD_W43_EXP
 #define VD_W43_EXP 0
 #endif
@@ -88,6 +88,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #endif
 #ifndef VD_W43_SB
 #define VD_W43_SB 12          /* MFMA step (of 18 per K tile) the tile barrier sits in front of */
+#endif
+#ifndef VD_W43_ORDER
+#define VD_W43_ORDER 0        /* work items an XCD runs together: 0 = 4 channel blocks x 8 tile groups, 1 = 8 x 4 (A/B builds) */
 #endif
 #ifndef VD_W43_UPF
 #define VD_W43_UPF 2          /* MFMA steps a U fragment is read ahead of its use (same-box A/B of 1 / 2 / 3, tests/probe/r04_pass7.sh: 2 and 3 are ~1 % ahead of 1) */
@@ -281,6 +284,15 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
         int t = n * G + (int)blockIdx.x;
         if ((G & 7) == 0 && (n + 1) * G <= p.nitems) t = n * G + ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
         if (t >= p.nitems) return false;
+#if VD_W43_ORDER == 1
+        // (A/B build only: 8 channel blocks x 4 tile groups per XCD -- every tile group's patch stream stays in ONE L2, every XCD streams the
+        //  U images of 8 blocks.  Measured against the 4 x 8 order below: tests/probe/r04_pass12.sh, FINDINGS round 4)
+        if ((p.ncb & 7) == 0 && (ngrp & 3) == 0) {
+            const int c = t >> 5, i = t & 31, ncg = p.ncb >> 3;
+            cb = (c % ncg) * 8 + (i & 7); grp = (c / ncg) * 4 + (i >> 3);
+            return true;
+        }
+#endif
         if ((p.ncb & 3) == 0 && (ngrp & 7) == 0) {
             const int c = t >> 5, i = t & 31, ncg = p.ncb >> 2;
             cb = (c % ncg) * 4 + (i & 3); grp = (c / ncg) * 8 + (i >> 2);
@@ -321,8 +333,8 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
             f32x4 acc[18][2];
 #pragma unroll
             for (int x = 0; x < 18; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (VD_W43_EXP != 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (EXP 6: what would hiding the first stage's latency buy?)
+            if (VD_W43_EXP != 6) __syncthreads(); else lds_barrier();
             if (nkt > 1) {
 #pragma unroll
                 for (int i = 0; i < PAFTER; ++i) issue_piece(i, 1, 1, cb);
