@@ -1,0 +1,49 @@
+"""Does the train step still LEARN with the F(4x4,3x3) forward in the path?  300 optimizer steps of the CIFAR-cond model on 4 fixed synthetic
+batches (fixed t / noise per batch, dropout on), loss every 25 steps -- once as shipped, once with VD_WINO43_FWD=0 in a second process.
+    python tests/probe/train_sanity.py            (prints both curves and their largest relative difference over the first 100 steps)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "v-diffusion-torch_amd"))
+    import torch
+    import bench
+    import v_diffusion
+    from v_diffusion.trainer import HotPathTrainer
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(7)
+    model = bench.build_model(dev).train()
+    gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), 50, "v", "fixed_medium", "snr_trunc", "mse",
+                                       intp_frac=0.3, w_guide=1.0, p_uncond=0.1)
+    tr = HotPathTrainer(model, gd, lr=2e-4, weight_decay=0.001, warmup=50, grad_norm=1.0, ema_decay=0.9999, use_ema=True)
+    g = torch.Generator(dev).manual_seed(11)
+    batches = []
+    for _ in range(4):
+        x = torch.rand((128, 3, 32, 32), device=dev, generator=g) * 2 - 1
+        y = torch.randint(1, 11, (128,), device=dev, generator=g).float()
+        t = torch.rand((128,), dtype=torch.float64, device=dev, generator=g)
+        n = torch.randn((128, 3, 32, 32), device=dev, generator=g)
+        batches.append((x, y, t, n))
+    out = []
+    for s in range(300):
+        x, y, t, n = batches[s % 4]
+        loss = tr.step(x, y.clone(), t=t.clone(), noise=n)
+        if s % 25 == 0 or s == 299:
+            out.append(round(float(loss), 5))
+    print("CURVE", out, flush=True)
+    sys.exit(0)
+
+curves = {}
+for name, env in (("F(4x4,3x3) forward", {}), ("F(2x2,3x3) forward", {"VD_WINO43_FWD": "0"})):
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("CURVE")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    curves[name] = eval(line[0][6:])
+    print(f"{name}: {curves[name]}")
+a, b = curves["F(4x4,3x3) forward"], curves["F(2x2,3x3) forward"]
+print("largest relative difference over the first 100 steps:", max(abs(p - q) / max(abs(q), 1e-9) for p, q in zip(a[:5], b[:5])))
+print("loss fell:", a[0], "->", a[-1], "|", b[0], "->", b[-1])
+assert a[-1] < 0.6 * a[0] and b[-1] < 0.6 * b[0], "the model did not learn the fixed batches"
