@@ -279,7 +279,8 @@ int vd_gn_apply_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, 
                     float* dfilm, float* dgamma, float* dbeta, int32_t accumulate_params,
                     int32_t nimg, int32_t H, int32_t W, int32_t C, int32_t G,
                     float* ws, size_t ws_bytes, void* stream);
-/* NPT * 10000 + TPB of the calling thread's last vd_gn_apply_bwd launch when it took the single-pass form gn_bwd_fused_kernel<NPT, TPB>,
+/* NPT * 10000 + TPB (+ 1000000 for the instantiation with non-temporal loads / stores: slabs of whole 128-byte pixel rows) of the calling
+ * thread's last vd_gn_apply_bwd launch when it took the single-pass form gn_bwd_fused_kernel<NPT, TPB, NT>,
  * -1 for the two-pass form (chan_reduce_kernel<1> + gn_bwd_finalize_kernel + gn_bwd_apply_kernel), 0 without a norm (plain resample
  * backward: gn_bwd_apply_kernel).  Profiling aid, like vd_gemm_last_tile. */
 int vd_gn_bwd_last_kernel(void);

@@ -14,6 +14,21 @@ namespace {
 
 constexpr int PPC = 128;     // pixels per reduction chunk
 
+// streaming accesses of the single-pass backward kernel: every byte is touched once per launch, so they may bypass the caches' retention
+// (non-temporal).  Same-box A/B (tests/probe/r04_pass13.sh): -4 ... -7 % for slabs whose pixel rows are whole 128-byte lines (32-channel
+// slabs: 32x32x256 105 -> 98 us, x512 189 -> 178), +19 % for 96-byte rows (24-channel slabs of C = 384), so the launcher instantiates NT only
+// for CS % 32 == 0; the apply pass (whole pixel rows) measured +-3 % either way and stays plain.
+template <bool NT>
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(float* p, f32x4 v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    else *reinterpret_cast<f32x4*>(p) = v;
+}
+
 struct ReduceArgs {
     const float* x; long long ldx;        // MODE 0/2: data ; MODE 1: forward input of the norm
     const float* dy; long long lddy;      // MODE 1: upstream gradient (output resolution)
@@ -529,7 +544,7 @@ struct FusedBwdArgs {
     BwdApplyArgs a; const float* gamma; const float* beta; const float* film; float* dfilm; float* pgb; int G, CS;
 };
 
-template <int NPT, int TPB>
+template <int NPT, int TPB, bool NT = false>
 __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f) {
     __shared__ float red[TPB][8];
     __shared__ float chs[2][128];        // per-channel S1 (sum dz), S2 (sum dz*xhat) ; later k*S1, k*S2
@@ -570,8 +585,8 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
                 const int pc = min(r + i * rows, HW - 1);
-                xin[i] = *reinterpret_cast<const f32x4*>(ximg + (long long)pc * p.ldx + c4);
-                dz[i] = *reinterpret_cast<const f32x4*>(dimg + (long long)pc * p.lddy + c4);
+                xin[i] = ld_stream<NT>(ximg + (long long)pc * p.ldx + c4);
+                dz[i] = ld_stream<NT>(dimg + (long long)pc * p.lddy + c4);
             }
         }
 #pragma unroll
@@ -685,18 +700,21 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int pix = r + i * rows;
-        if (pix < HW) *reinterpret_cast<f32x4*>(oimg + (long long)pix * f.a.lddx + c4) = dz[i];
+        if (pix < HW) st_stream<NT>(oimg + (long long)pix * f.a.lddx + c4, dz[i]);
     }
 }
 
-thread_local int g_last_gn_bwd = 0;   // NPT * 10000 + TPB of the last fused launch, -1 = two-pass form, 0 = no norm (plain resample)
+thread_local int g_last_gn_bwd = 0;   // NPT * 10000 + TPB (+ 1000000: non-temporal instantiation) of the last fused launch, -1 = two-pass form, 0 = no norm (plain resample)
 
 template <int TPB>
 void launch_fused_bwd(int npt, dim3 grid, hipStream_t st, const FusedBwdArgs& f) {
-    g_last_gn_bwd = (npt <= 1 ? 1 : (npt <= 2 ? 2 : (npt <= 4 ? 4 : 8))) * 10000 + TPB;
+    const bool nt = f.CS % 32 == 0 && npt > 2;   // whole 128-byte lines per pixel row: non-temporal loads / stores (see ld_stream)
+    g_last_gn_bwd = (npt <= 1 ? 1 : (npt <= 2 ? 2 : (npt <= 4 ? 4 : 8))) * 10000 + TPB + (nt ? 1000000 : 0);
     if (npt <= 1) hipLaunchKernelGGL((gn_bwd_fused_kernel<1, TPB>), grid, dim3(TPB), 0, st, f);
     else if (npt <= 2) hipLaunchKernelGGL((gn_bwd_fused_kernel<2, TPB>), grid, dim3(TPB), 0, st, f);
+    else if (npt <= 4 && nt) hipLaunchKernelGGL((gn_bwd_fused_kernel<4, TPB, true>), grid, dim3(TPB), 0, st, f);
     else if (npt <= 4) hipLaunchKernelGGL((gn_bwd_fused_kernel<4, TPB>), grid, dim3(TPB), 0, st, f);
+    else if (nt) hipLaunchKernelGGL((gn_bwd_fused_kernel<8, TPB, true>), grid, dim3(TPB), 0, st, f);
     else hipLaunchKernelGGL((gn_bwd_fused_kernel<8, TPB>), grid, dim3(TPB), 0, st, f);
 }
 

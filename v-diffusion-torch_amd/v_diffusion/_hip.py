@@ -523,7 +523,8 @@ class _TimedBytes:
 def _gn_bwd_name():
     k = lib().vd_gn_bwd_last_kernel()
     if k > 0:
-        return f"gn_bwd_fused_kernel<{k // 10000}, {k % 10000}>"
+        nt, k = k >= 1000000, k % 1000000
+        return f"gn_bwd_fused_kernel<{k // 10000}, {k % 10000}, {'true' if nt else 'false'}>"
     return "gn_bwd_apply_kernel (two-pass form)" if k < 0 else "gn_bwd_apply_kernel (resample)"
 
 
