@@ -649,6 +649,19 @@ __device__ __forceinline__ void a6(const f32x4 (&y)[4], f32x4 (&o)[6]) {
 #ifndef VD_W43_KBLOCK
 #define VD_W43_KBLOCK 1
 #endif
+// the transform pass writes V / dM once, the grouped GEMMs read them back right after: PLAIN stores.  Non-temporal ones (VD_W43_NT=1) measured
+// 8-10 % slower (0.164-0.173 vs 0.152 ms at 256 -> 256 @32x32, same-box A/B tests/probe/r04_pass15.sh) -- unlike the optimizer pass and the
+// GroupNorm backward, whose streams nobody reads back soon
+#ifndef VD_W43_NT
+#define VD_W43_NT 0
+#endif
+__device__ __forceinline__ void st_once(float* p, f32x4 v) {
+#if VD_W43_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 struct WgT43 {
     const float* x; long long ldx; const float* dy; long long lddy;
     float* V; float* dM;                       // [T/16][36][16][Cin], [T/16][36][16][Cout]: blocks of 16 tiles, the 36 planes of a block adjacent
@@ -686,8 +699,8 @@ __global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43
             bt6(col, o);                                            // V[a][b] = sum_p B^T[a][p] R[p][b]
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                *reinterpret_cast<f32x4*>(p.V + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
-                                                                : ((long long)(6 * a + b) * p.T + tile)) * p.Cin + c4) = o[a];
+                st_once(p.V + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
+                                             : ((long long)(6 * a + b) * p.T + tile)) * p.Cin + c4, o[a]);
         }
     } else {
         if (c4 >= p.Cout) return;
@@ -707,8 +720,8 @@ __global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43
             a6(col, o);                                             // dM[a][b] = sum_u A[a][u] R[u][b]
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                *reinterpret_cast<f32x4*>(p.dM + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
-                                                                 : ((long long)(6 * a + b) * p.T + tile)) * p.Cout + c4) = o[a];
+                st_once(p.dM + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
+                                              : ((long long)(6 * a + b) * p.T + tile)) * p.Cout + c4, o[a]);
         }
     }
 }
