@@ -89,6 +89,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #ifndef VD_W43_SB
 #define VD_W43_SB 12          /* MFMA step (of 18 per K tile) the tile barrier sits in front of */
 #endif
+#ifndef VD_W43_RES_AUX
+#define VD_W43_RES_AUX 0      /* cache policy of the residual loads: 0 = default, 2 = non-temporal (A/B builds: tests/probe/r04_pass16.sh) */
+#endif
 #ifndef VD_W43_ORDER
 #define VD_W43_ORDER 0        /* work items an XCD runs together: 0 = 4 channel blocks x 8 tile groups, 1 = 8 x 4 (A/B builds) */
 #endif
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                             for (int v = 0; v < 4; ++v) {
                                 RV[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
                                 if (p.res) RV[u][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rrs, (int)(((pixr + (unsigned)(u * p.W + v)) * (unsigned)p.ldr + n0r) * 4u), 0, 0));
+                                                          rrs, (int)(((pixr + (unsigned)(u * p.W + v)) * (unsigned)p.ldr + n0r) * 4u), 0, VD_W43_RES_AUX));
                             }
                     }
                     lds_barrier();                                  // (the residual loads stay in flight across it)
