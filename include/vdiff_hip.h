@@ -74,10 +74,15 @@ typedef struct vd_gemm_desc {
 /* replaces F.linear (modules.py:79-80), 1x1 F.conv2d (modules.py:141-144 <- unet.py:70,71,134), the two
  * einsum contractions of attention (unet.py:57,61-63) and all of their autograd backward GEMMs */
 int vd_gemm(const vd_gemm_desc* d, void* stream);
-/* ((TR*100 + KT)*1000 + BM)*1000 + BN of the calling thread's last vd_gemm / vd_conv3x3* launch (profiling aid: names the
- * kernel instantiation gemm_dma_kernel<BM,BN,a_kind,b_kind,splitk,KT,TR> the launch went to; TR = 1: transposed-accumulator
- * epilogue (launches without output statistics); KT = 0 means the register-staged fallback
- * gemm_kernel<BM,BN,a_kind,b_kind,splitk>) */
+/* ((F*100 + KT)*1000 + BM)*1000 + BN of the calling thread's last vd_gemm / vd_conv3x3* launch (profiling aid: names the
+ * kernel instantiation gemm_dma_kernel<BM,BN,a_kind,b_kind,splitk,KT,TR> the launch went to; F bit 0 = TR, transposed-accumulator
+ * epilogue (launches without output statistics); F >= 2: split-operand form, below; KT = 0 means the register-staged fallback
+ * gemm_kernel<BM,BN,a_kind,b_kind,splitk>).
+ * Environment, read once per process: VD_GEMM_SPLIT=1 (default 0) sends the 128-row tiles of vd_gemm and every vd_gemm_grouped_wgrad
+ * launch to the split-operand forms: each fp32 operand value is split exactly into three bf16 pieces in registers and the six piece
+ * products that reach 2^-24 of a.b run on the 16-bit matrix cores with fp32 accumulation.  Same results to fp32 rounding (error against
+ * fp64 0.6-0.9 of the fp32 MFMA chain's: tests/test_kernels_gpu.py::test_split_operand_gemm_forms_in_subprocess), 15-26 % shorter
+ * launches, -1 to -3 % on a train step (the part is power-bound: DESIGN.md section 3). */
 int vd_gemm_last_tile(void);
 /* `count` (<= 36) same-shape weight-gradient GEMMs in ONE launch -- the 1x1-convolution / linear weight gradients of the blocks of one
  * UNet level (autograd of modules.py:79-80,141-144 w.r.t. the weight), whose operands live in unrelated buffers:

@@ -23,6 +23,9 @@
 namespace {
 
 constexpr int KT = 32;   // K tile
+#ifndef VD_GEMM_SPLIT_DEFAULT
+#define VD_GEMM_SPLIT_DEFAULT 0
+#endif
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias; const float* R;
@@ -394,13 +397,46 @@ struct GroupPtrs { const float* A[VD_GROUP_MAX]; const float* B[VD_GROUP_MAX]; }
 struct NoGroup {};
 struct GroupOut { float* C[VD_GROUP_MAX]; float* cs[VD_GROUP_MAX]; };
 
-template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED = false>
+// SPL: fp32 products on the 16-bit matrix cores through split operands.  Every fp32 x is the exact sum of three bf16 pieces,
+// h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest even), and a.b = hh + hm + mh + mm + hl + lh up to terms below
+// 2^-24 |a.b| (ml, lm, ll), accumulated in fp32 by v_mfma_f32_32x32x16_bf16: six instructions of 32 cycles contract 16 k where the fp32
+// form needs eight of 64.  The split (5.5 vector instructions per element, in registers, after the same LDS-DMA tiles and fragment
+// reads) issues in the shadow of the MFMAs of the other waves of the SIMD.  Measured against fp64 (tests/probe/split_mfma.hip, K = 1 024
+// and 8 192, normal / positive / wide-range operands): relative L2 error 0.6-0.9 of the fp32 MFMA chain's, worst element 0.6-1.0 of it;
+// three products (hh, hm, mh) are 3-10x worse and are not used.  Same-box rates of the bare loop: 216 TFLOP/s fp32-equivalent against
+// 150 for the fp32 instruction (the chip's power limit, not the issue rate, bounds the 16-bit pipes on random data).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // {bf16(a), bf16(b)}, a in the low half (v_cvt_pk_bf16_f32)
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& H, bf16x8& M, bf16x8& L) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = x[2 * q], x1 = x[2 * q + 1];
+        const unsigned hp = pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xFFFF0000u);      // exact
+        const unsigned mp = pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xFFFF0000u);      // exact
+        h[q] = hp; m[q] = mp; l[q] = pk_bf16(s0, s1);
+    }
+    H = __builtin_bit_cast(bf16x8, h); M = __builtin_bit_cast(bf16x8, m); L = __builtin_bit_cast(bf16x8, l);
+}
+
+template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED = false, bool SPL = false>
 #ifndef VD_KT16_BLOCKS
 #define VD_KT16_BLOCKS 4
 #endif
-__global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma_kernel(const GemmArgs p,
+#ifndef VD_SPL_BLOCKS
+#define VD_SPL_BLOCKS 3       /* workgroups per CU of the split-operand KT = 16 forms (168 registers) */
+#endif
+__global__ __launch_bounds__(256, (KT == 16 ? (SPL ? VD_SPL_BLOCKS : VD_KT16_BLOCKS) : 2)) void gemm_dma_kernel(const GemmArgs p,
                                                                                           const std::conditional_t<GROUPED, GroupPtrs, NoGroup> gp) {
-    __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * KT];
+    constexpr int NBUF = 2;
+    __shared__ __attribute__((aligned(1024))) float smem[NBUF * (BM + BN) * KT];
     constexpr int MT = BM / 64, NT = BN / 64;
     constexpr int AIT = BM * KT / 1024, BIT = BN * KT / 1024;   // DMA pieces (1 KiB) per wave for A / B
     constexpr int A_LPR = BM / 4, B_LPR = BN / 4;        // lanes per k-row of a row-contiguous tile
@@ -604,7 +640,7 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
     };
     auto issue_tiles = [&](int buf, const Prep& P) {
         float* as = smem + buf * (BM * KT);
-        float* bs = smem + 2 * BM * KT + buf * (BN * KT);
+        float* bs = smem + NBUF * BM * KT + buf * (BN * KT);
         const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.pA, PB(p) & 1 ? 0 : (int)OOB);   // probe: timing-only build knob
         const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.pB, PB(p) & 2 ? 0 : (int)OOB);
 #pragma unroll
@@ -687,6 +723,87 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
                                    : __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
     };
 
+    // ---- split-operand form: a sub-step is 16 k (one 32x32x16 instruction deep); lane (li, lh) takes k = 16s + 8lh + j, j = 0..7
+    auto load_frags8 = [&](const float* as, const float* bs, int s, float (&fa)[MT][8], float (&fb)[NT][8]) {
+        if (A2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(as + (16 * s + 8 * lh + j) * BM + wm + 2 * li);
+                fa[0][j] = v[0]; fa[MT - 1][j] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = wm + 32 * a + li;
+                if (AK == VD_COL) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) fa[a][j] = as[(16 * s + 8 * lh + j) * BM + row];
+                } else {
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 4 * s + 2 * lh));
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(as + row_swz_t<KT>(row, 4 * s + 2 * lh + 1));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { fa[a][j] = q0[j]; fa[a][4 + j] = q1[j]; }
+                }
+            }
+        }
+        if (B2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(bs + (16 * s + 8 * lh + j) * BN + wn + 2 * li);
+                fb[0][j] = v[0]; fb[NT - 1][j] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int row = wn + 32 * b + li;
+                if (BK == VD_ROW) {
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(bs + row_swz_t<KT>(row, 4 * s + 2 * lh));
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(bs + row_swz_t<KT>(row, 4 * s + 2 * lh + 1));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { fb[b][j] = q0[j]; fb[b][4 + j] = q1[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) fb[b][j] = bs[(16 * s + 8 * lh + j) * BN + row];
+                }
+            }
+        }
+    };
+    auto compute_split = [&](int buf, int kt_prep, Prep& P) {
+        const float* as = smem + buf * (BM * KT);
+        const float* bs = smem + NBUF * BM * KT + buf * (BN * KT);
+        constexpr int S = KT / 16;
+        float fa[MT][8], fb[NT][8];
+        load_frags8(as, bs, 0, fa, fb);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s == 0) {
+                if (ISSUE_IN) issue_tiles(buf ^ 1, P);
+                prep_tiles(kt_prep, P);
+            }
+            bf16x8 ah[MT], am[MT], al[MT], bh[NT], bm[NT], bl[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) split8(fa[a], ah[a], am[a], al[a]);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) split8(fb[b], bh[b], bm[b], bl[b]);
+            if (AK == VD_COL && do_cs) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+                    csum[a] += ((fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3])) + ((fa[a][4] + fa[a][5]) + (fa[a][6] + fa[a][7]));
+            }
+            if (s + 1 < S) load_frags8(as, bs, s + 1, fa, fb);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+#define VD_MF(X, Y) acc[a][b] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[b], X[a], acc[a][b], 0, 0, 0) \
+                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[a], Y[b], acc[a][b], 0, 0, 0)
+                    VD_MF(al, bh); VD_MF(ah, bl); VD_MF(am, bm); VD_MF(am, bh); VD_MF(ah, bm); VD_MF(ah, bh);
+#undef VD_MF
+                }
+        }
+    };
+
     // software pipeline over the KT/8 sub-steps: the fragments of sub-step s+1 are requested BEFORE the MFMAs of
     // sub-step s, and sched_group_barrier spreads those LDS reads between the MFMAs so no wave sits on an lgkmcnt wait
     // at a sub-step boundary
@@ -765,7 +882,8 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma
         } else
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             if (!ISSUE_IN) issue_tiles(buf ^ 1, P);
-            compute(buf, kt + 2, P);
+            if constexpr (SPL) compute_split(buf, kt + 2, P);
+            else compute(buf, kt + 2, P);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             buf ^= 1;
@@ -1107,6 +1225,11 @@ bool use_tr(const GemmArgs& a, bool wgrad) {
     return a.sCb % 4 == 0 && a.sCh % 4 == 0 && a.slab_stride % 4 == 0;
 }
 
+// VD_GEMM_SPLIT (read once): 1 = the split-operand forms (SPL above) wherever they are built, 0 = fp32 MFMA everywhere
+static bool split_forms() {
+    static const int v = [] { const char* e = getenv("VD_GEMM_SPLIT"); return e ? atoi(e) : VD_GEMM_SPLIT_DEFAULT; }();
+    return v != 0;
+}
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     // the only tile with a KT = 16 instantiation; an unsplit conv weight gradient never takes it (ktile_for): those two
@@ -1114,7 +1237,19 @@ void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     constexpr bool has16 = BM == 128 && BN == 128 && !(BK == VD_IM2COL && !SPLITK);
     const bool k16 = has16 && ktile == 16;
     const bool tr = use_dma(a) && use_tr(a, BK == VD_IM2COL);
-    vd_g_last_tile = ((((tr ? 1 : 0) * 100 + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
+    // split-operand forms (SPL): the 128-row tiles of every operand kind without im2col addressing
+    constexpr bool has_spl = BM == 128 && AK != VD_IM2COL && BK != VD_IM2COL;
+    const bool spl = has_spl && use_dma(a) && split_forms();
+    vd_g_last_tile = ((((tr ? 1 : 0) * 100 + (spl ? 200 : 0) + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
+    if constexpr (has_spl) {
+        if (spl) {
+            if (k16 && tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
+            else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
+            else if (tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, true, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
+            else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, false, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
+            return;
+        }
+    }
     if (!use_dma(a)) hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK, SPLITK>), grid, dim3(256), 0, st, a);
     else if (k16 && tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true>), grid, dim3(256), 0, st, a, NoGroup{});
     else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false>), grid, dim3(256), 0, st, a, NoGroup{});
@@ -1230,8 +1365,10 @@ int run_gemm(const vd_gemm_desc& d, hipStream_t st) {
 
 template <int BM, int BN, int KTV = 32>
 void launch_grouped(const GemmArgs& a, const GroupPtrs& gp, dim3 grid, hipStream_t st) {
-    vd_g_last_tile = ((((1) * 100 + KTV) * 1000) + BM) * 1000 + BN;
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, KTV, true, true>), grid, dim3(256), 0, st, a, gp);
+    const bool spl = split_forms();
+    vd_g_last_tile = ((((spl ? 3 : 1) * 100 + KTV) * 1000) + BM) * 1000 + BN;
+    if (spl) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, KTV, true, true, true>), grid, dim3(256), 0, st, a, gp);
+    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, KTV, true, true>), grid, dim3(256), 0, st, a, gp);
 }
 // 128x128 tiles of a grouped launch with at least this many workgroups take the KT = 16 form (32 KB of LDS: four workgroups per CU)
 constexpr long long GROUPED_K16_MIN_WGS = 768;
