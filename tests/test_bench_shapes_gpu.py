@@ -864,3 +864,71 @@ def test_cifar_train_step_b128_rows_and_halves():
         worst = max(worst, err / max(ref.norm().item(), 1e-2 * gmax))
         assert err <= 2e-5 * ref.norm().item() + 2e-7 * gmax, f"{k}: B=128 vs mean of two B=64 halves rel-L2 {err / max(ref.norm().item(), 1e-30):.3e}"
     print(f"B=128 step: rows 0-7 dx err {d / sc:.2e} of scale; worst gradient rel-L2 vs the two B=64 halves {worst:.2e}")
+
+
+def test_celeba_train_step_b64_rows_and_halves():
+    """configs[4] trains CelebA at global batch 512 over 8 ranks: 64 rows per rank.  One CelebA(merged) train step at B = 64
+    (drop_rate = 0), tied to the oracle-checked B = 8 step (test_celeba_train_step_b8_vs_oracle uses the same inputs for rows 0-7)
+    through row independence and linearity, as test_cifar_train_step_b128_rows_and_halves does for configs[1]:
+      * per-sample loss, network output and input gradient of rows 0-7 equal those of the B = 8 step (<= 2e-5 of scale);
+      * the gradient of the mean loss over 64 rows is the mean of the gradients of its two B = 32 halves (relative L2 <= 2e-5).
+    B = 64 puts the 64x64 level's weight gradients on 16 384 tiles, the 8x8 level's on 256 (below the F(4x4,3x3) weight-gradient
+    threshold: fused F(2x2,3x3)), and the attention blocks on L = 4096 ... 64 with 64 x 3 heads per launch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import v_diffusion
+    from oracle import detrand
+    from oracle.cases import CELEBA, make_inputs, make_weights
+    cfg = dict(CELEBA, drop_rate=0.0)
+    B = 64
+    sd = make_weights(cfg)
+    model = v_diffusion.UNet(**cfg)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    x8, t8, y8 = make_inputs(cfg, 8, 64, "multi", seed=13)               # rows 0-7: the inputs of the oracle-checked B = 8 step
+    xr, tr, yr = make_inputs(cfg, B - 8, 64, "multi", seed=14)
+    x0 = torch.cat([x8, xr]).clamp(-1, 1)
+    t, y = torch.cat([t8, tr]), torch.cat([y8, yr])
+    noise = torch.cat([detrand.normal("noise", tuple(x8.shape), 13), detrand.normal("noise", tuple(xr.shape), 14)])
+    gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), 50, "v", "fixed_medium", "snr_trunc",
+                                       "mse", intp_frac=0.3, w_guide=1.0, p_uncond=0.0)
+
+    def run(rows):
+        for p in model.parameters():
+            p.grad = None
+        loss = gd.train_loss(model, x0[rows].to(DEV), t[rows].to(DEV), y[rows].to(DEV).clone(), noise[rows].to(DEV))
+        loss.mean().backward()
+        torch.cuda.synchronize()
+        return loss.detach().cpu(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    cot = detrand.normal("cot", tuple(x0.shape), 19)
+
+    def run_dx(rows):
+        xin = noise[rows].to(DEV).requires_grad_(True)
+        out = model(xin, t[rows].to(DEV), y[rows].to(DEV).clone())
+        (out * cot[rows].to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().cpu(), xin.grad.detach().cpu()
+
+    full = torch.arange(B)
+    l_full, g_full = run(full)
+    l_8, _ = run(full[:8])
+    assert torch.allclose(l_full[:8], l_8, rtol=2e-5, atol=1e-7), (l_full[:8], l_8)
+    o_full, dx_full = run_dx(full)
+    o_8, dx_8 = run_dx(full[:8])
+    assert (o_full[:8] - o_8).abs().max().item() <= 2e-5 * max(o_8.abs().max().item(), 1.0)
+    sc = dx_8.abs().max().item()
+    d = (dx_full[:8] - dx_8).abs().max().item()
+    assert d <= 2e-5 * sc, f"dx of rows 0-7: B=64 vs B=8 differ by {d:.3e} on scale {sc:.3e}"
+    del o_full, dx_full
+    l_a, g_a = run(full[:32])
+    l_b, g_b = run(full[32:])
+    assert torch.allclose(l_full, torch.cat([l_a, l_b]), rtol=2e-5, atol=1e-7)
+    gmax = max(v.norm().item() for v in g_full.values())
+    worst = 0.0
+    for k, g in g_full.items():
+        ref = 0.5 * (g_a[k].double() + g_b[k].double())
+        err = (g.double() - ref).norm().item()
+        worst = max(worst, err / max(ref.norm().item(), 1e-2 * gmax))
+        assert err <= 2e-5 * ref.norm().item() + 2e-7 * gmax, f"{k}: B=64 vs mean of two B=32 halves rel-L2 {err / max(ref.norm().item(), 1e-30):.3e}"
+    print(f"CelebA B=64 step: rows 0-7 dx err {d / sc:.2e} of scale; worst gradient rel-L2 vs the two B=32 halves {worst:.2e}")

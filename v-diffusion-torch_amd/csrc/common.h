@@ -24,7 +24,8 @@ int vd_cu_count(void);                       // compute units of the calling thr
 int vd_persistent_cus(void);                 // vd_cu_count() minus the CUs reserved for other streams' kernels (vd_set_reserved_cus)
 int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count, int32_t M,
                                int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws, size_t ws_bytes,
-                               void* stream, int64_t a_kblk, int64_t b_kblk);      // gemm.hip: grouped weight-gradient GEMMs on K-blocked operands
+                               void* stream, int64_t a_kblk, int64_t b_kblk, int32_t slabs_only);   // gemm.hip: grouped weight-gradient GEMMs on K-blocked operands
+int vd_gemm_grouped_wgrad_used_slabs(int32_t count, int32_t M, int32_t N, int32_t K, int32_t splitk);   // slabs such a launch fills
 extern thread_local int vd_g_last_tile;      // code of the calling thread's last matmul-shaped launch (vd_gemm_last_tile)
 
 #define VD_REQUIRE(cond, ...)                                   \

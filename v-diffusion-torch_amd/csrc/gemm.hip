@@ -1409,17 +1409,29 @@ extern "C" size_t vd_gemm_grouped_wgrad_ws_bytes(int32_t count, int32_t M, int32
  * GemmArgs): the 36 planes of the F(4x4,3x3) weight gradient interleave block by block so that its transform pass writes one contiguous run */
 int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
                                int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws,
-                               size_t ws_bytes, void* stream, int64_t a_kblk, int64_t b_kblk);
+                               size_t ws_bytes, void* stream, int64_t a_kblk, int64_t b_kblk, int32_t slabs_only);
 
 extern "C" int vd_gemm_grouped_wgrad(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
                                      int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws,
                                      size_t ws_bytes, void* stream) {
-    return vd_gemm_grouped_wgrad_kblk(A, B, C, colsum, count, M, N, K, lda, ldb, ldc, splitk, ws, ws_bytes, stream, 0, 0);
+    return vd_gemm_grouped_wgrad_kblk(A, B, C, colsum, count, M, N, K, lda, ldb, ldc, splitk, ws, ws_bytes, stream, 0, 0, 0);
 }
 
+/* slabs a grouped launch of this shape fills (<= splitk): the launcher's own plan, for callers that reduce the slabs themselves */
+int vd_gemm_grouped_wgrad_used_slabs(int32_t count, int32_t M, int32_t N, int32_t K, int32_t splitk) {
+    const int S = splitk > 1 ? splitk : 1;
+    const int tile = choose_tile(M, N, false, (long long)count * S, 0);
+    const long long nm = (M + TILES[tile].bm - 1) / TILES[tile].bm, nn = (N + TILES[tile].bn - 1) / TILES[tile].bn;
+    const bool k16 = tile == 0 && nm * nn * count * S >= GROUPED_K16_MIN_WGS;
+    const int kt_total = k16 ? (K + 15) / 16 : (K + 31) / 32, per = (kt_total + S - 1) / S;
+    return (kt_total + per - 1) / per;
+}
+
+/* slabs_only != 0: stop after the split-K launch -- slab z of entry e is left at ws + (e * used + z) * M * N, its column sums at
+ * ws + count * used * M * N + (e * used + z) * M, used = vd_gemm_grouped_wgrad_used_slabs(...); C / colsum entries are not written */
 int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, float* const* C, float* const* colsum, int32_t count,
                                int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t splitk, float* ws,
-                               size_t ws_bytes, void* stream, int64_t a_kblk, int64_t b_kblk) {
+                               size_t ws_bytes, void* stream, int64_t a_kblk, int64_t b_kblk, int32_t slabs_only) {
     VD_REQUIRE(A && B && C && count > 0 && count <= VD_GROUP_MAX, "vd_gemm_grouped_wgrad: 1..%d entries (got %d)", VD_GROUP_MAX, count);
     VD_REQUIRE(M > 0 && N > 0 && K > 0 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc >= N,
                "vd_gemm_grouped_wgrad: M, N, lda, ldb must be multiples of 4 (M=%d N=%d)", M, N);
@@ -1460,6 +1472,10 @@ int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, flo
     else if (tile == 2) launch_grouped<64, 128>(a, gp, grid, st);
     else launch_grouped<64, 64>(a, gp, grid, st);
     VD_LAUNCH_CHECK("gemm_dma_kernel(grouped)");
+    if (slabs_only) {
+        VD_REQUIRE(used == vd_gemm_grouped_wgrad_used_slabs(count, M, N, K, splitk), "vd_gemm_grouped_wgrad: slab plan mismatch");
+        return 0;
+    }
     const long long tot = (long long)M * N;
     hipLaunchKernelGGL(reduce_slabs_grouped_kernel, dim3((unsigned)((tot + 255) / 256), (unsigned)count), dim3(256), 0, st, ws, used,
                        a.slab_stride, M, N, go, (long long)ldc, cpart);

@@ -775,6 +775,71 @@ __global__ __launch_bounds__(256) void wino43_wgrad_finish_kernel(const float* d
     }
 }
 
+// Wide layers (Cout x Cin >= FUSED_FINISH_MIN elements per plane) sum the split-K slabs of the 36 grouped GEMMs in the fold itself (fixed
+// order z = 0 .. S-1, fp32: bitwise what reduce_slabs_grouped_kernel into dU followed by the kernel above gives, without writing and
+// re-reading dU and one launch shorter): slab z of plane e at slabs + (e * S + z) * Cout * Cin, its column sums at cpart + (e * S + z) * Cout.
+// Block (64 elements, 6 columns b): thread (x, b) sums the slabs of the six planes (a, b) of element x -- 6 x S loads in six independent
+// chains, lanes = consecutive elements -- and folds them along a; the three rows meet through LDS and threads b < 3 fold row b along
+// the columns.  Same-box against the two passes (reduction + fold, ms, B = 128): 768 -> 768 @8x8 0.234 vs 0.296, 1536 -> 768 0.403 vs
+// 0.516, 576 -> 576 @16x16 0.577 vs 0.610, 1152 -> 576 0.903 vs 0.959, 384 -> 384 @32x32 0.708 vs 0.726; narrow layers have too few
+// elements to hide the load latency this way (256 -> 256: +0.009, 192 -> 192 @64x64 with 24 slabs: +0.06; 16-byte loads on a quarter of the
+// threads were slower still) and keep the two passes.
+constexpr long long FUSED_FINISH_MIN = 131072;
+__global__ __launch_bounds__(384) void wino43_wgrad_reduce_finish_kernel(const float* slabs, const float* cpart, int S, int Cout, int Cin,
+                                                                         int Cout_w, int Cin_w, float* dw, float* dbias, int accumulate) {
+    __shared__ float tsh[3][6][64];
+    const int x = threadIdx.x, b = threadIdx.y;
+    const long long idx = (long long)blockIdx.x * 64 + x;
+    if (dbias && b == 0 && idx < Cout_w) {
+        const double pv[6] = {-1.0 / 9, 8.0 / 9, 0.0, 2.0 / 9, 0.0, -1.0 / 8};
+        double c = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb)
+                if (pv[a] != 0.0 && pv[bb] != 0.0) {
+                    float cs = 0.f;
+                    for (int z = 0; z < S; ++z) cs += cpart[((long long)(6 * a + bb) * S + z) * Cout + idx];
+                    c += pv[a] * pv[bb] * (double)cs;
+                }
+        dbias[idx] = accumulate ? dbias[idx] + (float)c : (float)c;
+    }
+    const long long plane = (long long)Cout * Cin;
+    const bool in = idx < plane;
+    constexpr float g0 = 64.f / 81, g12 = 128.f / 243, g34 = 32.f / 243, h12 = 32.f / 81, h34 = 16.f / 81, k = 8.f / 27;
+    {
+        float u[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (in) {
+            const float* sl = slabs + (long long)b * S * plane + idx;
+            const long long astep = 6LL * S * plane;
+            for (int z = 0; z < S; ++z) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) u[a] += sl[a * astep + z * plane];
+            }
+        }
+        const float s12 = u[1] + u[2], d12 = u[2] - u[1], s34 = u[3] + u[4], d34 = u[3] - u[4];
+        tsh[0][b][x] = g0 * u[0] - g12 * s12 + g34 * s34;
+        tsh[1][b][x] = h12 * d12 + h34 * d34;
+        tsh[2][b][x] = k * (s34 - s12) + u[5];
+    }
+    __syncthreads();
+    if (!in || b >= 3) return;
+    const int co = (int)(idx / Cin), ci = (int)(idx - (long long)co * Cin);
+    if (co >= Cout_w || ci >= Cin_w) return;
+    const int r = b;
+    float t[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) t[c] = tsh[r][c][x];
+    const float s12 = t[1] + t[2], d12 = t[2] - t[1], s34 = t[3] + t[4], d34 = t[3] - t[4];
+    const float w0 = g0 * t[0] - g12 * s12 + g34 * s34;
+    const float w1 = h12 * d12 + h34 * d34;
+    const float w2 = k * (s34 - s12) + t[5];
+    float* o = dw + ((long long)co * Cin_w + ci) * 9 + 3 * r;
+    o[0] = accumulate ? o[0] + w0 : w0;
+    o[1] = accumulate ? o[1] + w1 : w1;
+    o[2] = accumulate ? o[2] + w2 : w2;
+}
+
 struct Wg43Plan { bool ok; int T, S; size_t v_f, m_f, u_f, cs_f, gemm_bytes; };
 Wg43Plan wg43_plan(int nimg, int H, int W, int Cin, int Cout) {
     Wg43Plan g = {};
@@ -930,7 +995,8 @@ extern "C" size_t vd_conv3x3_wgrad_wino43_ws_bytes(int32_t nimg, int32_t H, int3
     return (g.v_f + g.m_f + g.u_f + g.cs_f) * sizeof(float) + g.gemm_bytes;
 }
 
-/* phases (per-kernel timing): 1 = transforms, 2 = the 36 grouped GEMMs, 4 = finish; 7 = all */
+/* phases (per-kernel timing): 1 = transforms, 2 = the 36 grouped GEMMs (+ the slab reduction of narrow layers), 4 = G^T . G fold (+ the slab
+ * reduction of wide layers: FUSED_FINISH_MIN); 7 = all */
 static int wgrad43_impl(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W, int32_t Cin,
                         int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w, int32_t Cout_w, int32_t accumulate, float* ws,
                         size_t ws_bytes, void* stream, int phases) {
@@ -962,14 +1028,21 @@ static int wgrad43_impl(const float* xin, int64_t ldx, const float* dy, int64_t 
             C[e] = dU + (size_t)e * Cout * Cin; colsum[e] = cs + (size_t)e * Cout;
         }
         const int rc = vd_gemm_grouped_wgrad_kblk(A, B, C, colsum, 36, Cout, Cin, g.T, Cout, Cin, Cin, g.S, gws, g.gemm_bytes, stream,
-                                                  VD_W43_KBLOCK ? 36LL * 16 * Cout : 0, VD_W43_KBLOCK ? 36LL * 16 * Cin : 0);
+                                                  VD_W43_KBLOCK ? 36LL * 16 * Cout : 0, VD_W43_KBLOCK ? 36LL * 16 * Cin : 0,
+                                                  (long long)Cout * Cin >= FUSED_FINISH_MIN ? 1 : 0);
         if (rc) return rc;
         g_last43w = g.S;
     }
     if (phases & 4) {
         const long long tot = (long long)Cout * Cin;
-        hipLaunchKernelGGL(wino43_wgrad_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dU, cs, Cout, Cin, Cout_w, Cin_w,
-                           dw_oihw, dbias, accumulate);
+        if (tot >= FUSED_FINISH_MIN) {
+            const int used = vd_gemm_grouped_wgrad_used_slabs(36, Cout, Cin, g.T, g.S);
+            hipLaunchKernelGGL(wino43_wgrad_reduce_finish_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64, 6), 0, st, gws,
+                               gws + (size_t)36 * used * Cout * Cin, used, Cout, Cin, Cout_w, Cin_w, dw_oihw, dbias, accumulate);
+        } else {
+            hipLaunchKernelGGL(wino43_wgrad_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dU, cs, Cout, Cin, Cout_w, Cin_w,
+                               dw_oihw, dbias, accumulate);
+        }
         VD_LAUNCH_CHECK("wino43_wgrad_finish_kernel");
     }
     return 0;
@@ -984,7 +1057,7 @@ extern "C" int vd_conv3x3_wgrad_wino43(const float* xin, int64_t ldx, const floa
 extern "C" int vd_conv3x3_wgrad_wino43_phase(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H,
                                              int32_t W, int32_t Cin, int32_t Cout, float* dw_oihw, float* dbias, int32_t Cin_w,
                                              int32_t Cout_w, int32_t accumulate, float* ws, size_t ws_bytes, int32_t phase, void* stream) {
-    VD_REQUIRE(phase == 1 || phase == 2 || phase == 4, "vd_conv3x3_wgrad_wino43_phase: phase must be 1 (transforms), 2 (GEMMs) or 4 (finish)");
+    VD_REQUIRE(phase == 1 || phase == 2 || phase == 4, "vd_conv3x3_wgrad_wino43_phase: phase must be 1 (transforms), 2 (GEMMs) or 4 (reduction + finish)");
     return wgrad43_impl(xin, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw_oihw, dbias, Cin_w, Cout_w, accumulate, ws, ws_bytes, stream, phase);
 }
 
