@@ -79,7 +79,7 @@ int vd_gemm(const vd_gemm_desc* d, void* stream);
  * epilogue (launches without output statistics); F >= 2: split-operand form, below; KT = 0 means the register-staged fallback
  * gemm_kernel<BM,BN,a_kind,b_kind,splitk>).
  * Environment, read once per process: VD_GEMM_SPLIT=1 (default 0) sends the 128-row tiles of vd_gemm and every vd_gemm_grouped_wgrad
- * launch to the split-operand forms: each fp32 operand value is split exactly into three bf16 pieces in registers and the six piece
+ * launch to the split-operand forms (gemm_split_kernel<...>): each fp32 operand value is split exactly into three bf16 pieces in registers and the six piece
  * products that reach 2^-24 of a.b run on the 16-bit matrix cores with fp32 accumulation.  Same results to fp32 rounding (error against
  * fp64 0.6-0.9 of the fp32 MFMA chain's: tests/test_kernels_gpu.py::test_split_operand_gemm_forms_in_subprocess), 15-26 % shorter
  * launches, -1 to -3 % on a train step (the part is power-bound: DESIGN.md section 3). */

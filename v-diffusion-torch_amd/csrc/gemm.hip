@@ -426,15 +426,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& H, bf16x8& M
     H = __builtin_bit_cast(bf16x8, h); M = __builtin_bit_cast(bf16x8, m); L = __builtin_bit_cast(bf16x8, l);
 }
 
-template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED = false, bool SPL = false>
 #ifndef VD_KT16_BLOCKS
 #define VD_KT16_BLOCKS 4
 #endif
 #ifndef VD_SPL_BLOCKS
 #define VD_SPL_BLOCKS 3       /* workgroups per CU of the split-operand KT = 16 forms (168 registers) */
 #endif
-__global__ __launch_bounds__(256, (KT == 16 ? (SPL ? VD_SPL_BLOCKS : VD_KT16_BLOCKS) : 2)) void gemm_dma_kernel(const GemmArgs p,
-                                                                                          const std::conditional_t<GROUPED, GroupPtrs, NoGroup> gp) {
+// the kernel body; instantiated by gemm_dma_kernel (SPL = false: fp32 MFMA) and gemm_split_kernel (SPL = true) below
+template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED, bool SPL>
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& p, const std::conditional_t<GROUPED, GroupPtrs, NoGroup>& gp) {
     constexpr int NBUF = 2;
     __shared__ __attribute__((aligned(1024))) float smem[NBUF * (BM + BN) * KT];
     constexpr int MT = BM / 64, NT = BN / 64;
@@ -1043,6 +1043,18 @@ __global__ __launch_bounds__(256, (KT == 16 ? (SPL ? VD_SPL_BLOCKS : VD_KT16_BLO
     stamp_end();
 }
 
+template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED = false>
+__global__ __launch_bounds__(256, (KT == 16 ? VD_KT16_BLOCKS : 2)) void gemm_dma_kernel(const GemmArgs p,
+                                                                                          const std::conditional_t<GROUPED, GroupPtrs, NoGroup> gp) {
+    gemm_dma_body<BM, BN, AK, BK, SPLITK, KT, TR, GROUPED, false>(p, gp);
+}
+// the split-operand forms (VD_GEMM_SPLIT=1): same tiles, same LDS-DMA staging, same epilogues, 16-bit MFMA on three bf16 pieces per operand
+template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED = false>
+__global__ __launch_bounds__(256, (KT == 16 ? VD_SPL_BLOCKS : 2)) void gemm_split_kernel(const GemmArgs p,
+                                                                                           const std::conditional_t<GROUPED, GroupPtrs, NoGroup> gp) {
+    gemm_dma_body<BM, BN, AK, BK, SPLITK, KT, TR, GROUPED, true>(p, gp);
+}
+
 // out (+)= sum over slabs; optional OIHW transposition for the conv weight gradient
 __global__ void reduce_slabs_kernel(const float* slabs, int S, long long slab_stride, int M, int N, float* out,
                                     long long ldo, int accumulate, float alpha, const float* cpart, float* colsum,
@@ -1243,10 +1255,10 @@ void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     vd_g_last_tile = ((((tr ? 1 : 0) * 100 + (spl ? 200 : 0) + (use_dma(a) ? (k16 ? 16 : 32) : 0)) * 1000) + BM) * 1000 + BN;
     if constexpr (has_spl) {
         if (spl) {
-            if (k16 && tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
-            else if (k16) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
-            else if (tr) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, true, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
-            else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AK, BK, SPLITK, 32, false, false, true>), grid, dim3(256), 0, st, a, NoGroup{});
+            if (k16 && tr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), true>), grid, dim3(256), 0, st, a, NoGroup{});
+            else if (k16) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AK, BK, SPLITK, (has16 ? 16 : 32), false>), grid, dim3(256), 0, st, a, NoGroup{});
+            else if (tr) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AK, BK, SPLITK, 32, true>), grid, dim3(256), 0, st, a, NoGroup{});
+            else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, AK, BK, SPLITK, 32, false>), grid, dim3(256), 0, st, a, NoGroup{});
             return;
         }
     }
@@ -1367,7 +1379,7 @@ template <int BM, int BN, int KTV = 32>
 void launch_grouped(const GemmArgs& a, const GroupPtrs& gp, dim3 grid, hipStream_t st) {
     const bool spl = split_forms();
     vd_g_last_tile = ((((spl ? 3 : 1) * 100 + KTV) * 1000) + BM) * 1000 + BN;
-    if (spl) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, KTV, true, true, true>), grid, dim3(256), 0, st, a, gp);
+    if (spl) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, VD_COL, VD_COL, true, KTV, true, true>), grid, dim3(256), 0, st, a, gp);
     else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, VD_COL, VD_COL, true, KTV, true, true>), grid, dim3(256), 0, st, a, gp);
 }
 // 128x128 tiles of a grouped launch with at least this many workgroups take the KT = 16 form (32 KB of LDS: four workgroups per CU)

@@ -207,9 +207,9 @@ class _Timed:
             # hundreds digit of the K-tile group: 1 = transposed epilogue, 2 = split-operand form (VD_GEMM_SPLIT=1), 3 = both
             flags, kt, bm, bn = t // 100000000, (t // 1000000) % 100, (t // 1000) % 1000, t % 1000
             tr, spl = flags & 1, flags >= 2
-            name = self.name.format(tile=f"{bm}, {bn}", kt=f"{kt}, {'true' if tr else 'false'}" + (", false, true" if spl else ""))
-            if spl and name.endswith("true, true>"):            # (grouped launches name their own tail)
-                name = name[:-1] + ", true>"
+            name = self.name.format(tile=f"{bm}, {bn}", kt=f"{kt}, {'true' if tr else 'false'}")
+            if spl:
+                name = name.replace("gemm_dma_kernel", "gemm_split_kernel")
             if kt == 0:
                 name = name.replace("gemm_dma_kernel", "gemm_kernel").replace(", 0, false>", ">")
             PROFILE.append((name, self.flops, self.e0, self.e1))
