@@ -181,7 +181,7 @@ int vd_conv3x3_wino43_fwd(const float* xin, int64_t ldx, const float* U43f, cons
  * ([36][tiles][channels], 2.25x the size of dY / x each), the 36 GEMMs over the tile index run as one vd_gemm_grouped_wgrad launch (1.78x fewer
  * MFMA cycles than vd_conv3x3_wgrad_wino), a small kernel folds G^T . G into OIHW; the bias gradient is the column sum of plane (1,1).
  * Same arguments and result as vd_conv3x3_wgrad_wino (accumulate, padded dims, deterministic).  _supported: H, W, Cin, Cout multiples
- * of 4, at least 512 tiles of 4x4 outputs (8x8 images at batch 128).  _phase: 1 = transforms, 2 = GEMMs (+ slab reduction of layers below 131 072 weights per plane), 4 = finish (+ slab reduction of wider layers). */
+ * of 4, at least 512 tiles of 4x4 outputs (8x8 images at batch 128).  _phase: 1 = transforms, 2 = GEMMs (+ slab reduction of layers below 147 456 = 384 x 384 weights per plane), 4 = finish (+ slab reduction of wider layers). */
 int vd_conv3x3_wgrad_wino43_supported(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int64_t ldx, int64_t lddy);
 size_t vd_conv3x3_wgrad_wino43_ws_bytes(int32_t nimg, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int vd_conv3x3_wgrad_wino43(const float* xin, int64_t ldx, const float* dy, int64_t lddy, int32_t nimg, int32_t H, int32_t W,

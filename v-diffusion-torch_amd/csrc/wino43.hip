@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void wino43_wgrad_finish_kernel(const float* d
     }
 }
 
-// Wide layers (Cout x Cin >= FUSED_FINISH_MIN elements per plane) sum the split-K slabs of the 36 grouped GEMMs in the fold itself (fixed
+// Wide layers (Cout x Cin >= FUSED_FINISH_MIN = 384 x 384 elements per plane) sum the split-K slabs of the 36 grouped GEMMs in the fold itself (fixed
 // order z = 0 .. S-1, fp32: bitwise what reduce_slabs_grouped_kernel into dU followed by the kernel above gives, without writing and
 // re-reading dU and one launch shorter): slab z of plane e at slabs + (e * S + z) * Cout * Cin, its column sums at cpart + (e * S + z) * Cout.
 // Block (64 elements, 6 columns b): thread (x, b) sums the slabs of the six planes (a, b) of element x -- 6 x S loads in six independent
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void wino43_wgrad_finish_kernel(const float* d
 // 0.516, 576 -> 576 @16x16 0.577 vs 0.610, 1152 -> 576 0.903 vs 0.959, 384 -> 384 @32x32 0.708 vs 0.726; narrow layers have too few
 // elements to hide the load latency this way (256 -> 256: +0.009, 192 -> 192 @64x64 with 24 slabs: +0.06; 16-byte loads on a quarter of the
 // threads were slower still) and keep the two passes.
-constexpr long long FUSED_FINISH_MIN = 131072;
+constexpr long long FUSED_FINISH_MIN = 147456;      // 384 x 384 (512 -> 256 measured equal at 32x32 and 0.015 ms slower at 16x16: two passes)
 __global__ __launch_bounds__(384) void wino43_wgrad_reduce_finish_kernel(const float* slabs, const float* cpart, int S, int Cout, int Cin,
                                                                          int Cout_w, int Cin_w, float* dw, float* dbias, int accumulate) {
     __shared__ float tsh[3][6][64];
