@@ -435,7 +435,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[dev_index])       # (names the device: no "using the current device" guess inside RCCL)
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     B = args.batch
