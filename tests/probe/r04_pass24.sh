@@ -1,5 +1,6 @@
 #!/bin/bash
 # persistent grids that fill their rounds evenly (VD_EVEN_ROUNDS=1, default) vs one workgroup per CU (0): Winograd tests, CelebA + CIFAR step A/B
+# (record of a measurement: the VD_EVEN_ROUNDS switch existed only in the build this script measured, see FINDINGS.md round 4; it was not kept)
 mkdir -p gpurun_out/r4y
 timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_bench_shapes_gpu.py -q -m gpu -x -k "wino or reserved" > gpurun_out/r4y/tests.txt 2>&1; tail -2 gpurun_out/r4y/tests.txt
 for rnd in 1 2; do
