@@ -1161,6 +1161,9 @@ WGRAD43_CASES = [  # nimg, H, W, Cin, Cout, Cin_w, Cout_w, ldx_extra, lddy_extra
     (64, 16, 16, 96, 32, 96, 32, 0, 0),        # 16x16 images
     (20, 32, 32, 4, 32, 3, 32, 0, 0), (20, 32, 32, 32, 4, 32, 3, 0, 0),      # padded thin sides
     (4, 64, 64, 192, 192, 192, 192, 0, 0),
+    # >= 384 x 384 weights per plane: the fold kernel sums the split-K slabs itself (wino43_wgrad_reduce_finish_kernel) -- accumulate mode,
+    # real dims below the padded ones on both sides, row pitches above the channel counts
+    (32, 16, 16, 384, 388, 381, 386, 8, 4), (8, 32, 32, 512, 384, 512, 384, 0, 0),
 ]
 
 
