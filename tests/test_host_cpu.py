@@ -472,3 +472,62 @@ def test_device_running_statistics_matches_reference_contract():
     assert dev.count == 0 and all(v == 0 for v in dev.stats.values())
     dev.update(2, loss=3.0)
     assert dev.extract()["loss"] == 1.5
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# chain of autograd nodes (models/unet.py::_SegFn): the mechanics on CPU with a stand-in for the engine's backward generator
+import sys as _sys
+_sys.path.insert(0, os.path.join(ROOT, "tests"))
+from chain_stub import ChainStub as _ChainStub      # noqa: E402  (tests/chain_stub.py: shared with the two-rank DDP test)
+
+
+def test_autograd_chain_hands_gradients_over_segment_by_segment():
+    m = _ChainStub()
+    for k, p in m.named_parameters():
+        p.register_hook(lambda g, k=k: m.log.append(f"grad {k}"))
+    x = torch.ones(2, 3, requires_grad=True)
+    out = m(x)
+    assert torch.equal(out, x.detach() * 2)
+    out.sum().backward()
+    # every segment's gradients reach their hooks (= DDP's reducer) BEFORE the next segment's kernels are launched
+    assert m.log == ["kernels c", "grad c", "kernels b-part", "kernels b", "grad b", "kernels a", "closed", "grad a"], m.log
+    assert torch.equal(m.c.grad, torch.full((4,), 6.0)) and torch.equal(m.b.grad, torch.full((2,), 12.0))
+    assert torch.equal(m.a.grad, torch.full((3,), 18.0)) and torch.equal(x.grad, torch.full((2, 3), 5.0))
+    with pytest.raises(RuntimeError, match="called twice"):
+        m.log.clear()
+        out2 = m(x)
+        out2.sum().backward(retain_graph=True)
+        out2.sum().backward()
+
+
+def test_autograd_chain_two_forwards_one_backward_and_frozen_prefix():
+    m = _ChainStub()
+    x = torch.ones(2, 3)
+    (m(x).sum() + 2 * m(x).sum()).backward()                            # two passes of one engine inside one autograd run
+    assert torch.equal(m.c.grad, torch.full((4,), 6.0 + 12.0)) and torch.equal(m.a.grad, torch.full((3,), 18.0 + 36.0))
+    assert m.active is None
+    # input without gradient and the first segment's parameters frozen: nothing upstream of segment b takes part, the pass ends there
+    m2 = _ChainStub()
+    m2.a.requires_grad_(False)
+    m2(x).sum().backward()
+    assert m2.a.grad is None and torch.equal(m2.b.grad, torch.full((2,), 12.0))
+    assert "kernels a" not in m2.log and m2.log[-1] == "closed" and m2.active is None
+
+
+def test_grad_segments_cover_the_completion_order():
+    """the cut points of the chain are the engine's progress points; segments partition completion_order() in order"""
+    import v_diffusion
+    from v_diffusion.engine import UNetEngine
+    for cfg in (dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2, 2], num_res_blocks=2, apply_attn=[False, True, True],
+                     num_classes=10), dict(in_channels=3, hid_channels=32, out_channels=6, ch_multipliers=[1, 2], num_res_blocks=1,
+                                           apply_attn=[False, False], num_classes=5, multitags=True)):
+        model = v_diffusion.UNet(**cfg)
+        eng = UNetEngine(model)
+        segs = eng.grad_segments()
+        assert [n for _, names in segs for n in names] == eng.completion_order()
+        pts = eng.progress_points()
+        assert [b for b, _ in segs] == [p for p in pts if p not in ("in_conv.bias", None)] + [None]
+        assert len(segs) == 2 * len(cfg["ch_multipliers"]) + 3            # out_conv, up levels, middle, down levels, the rest
+        assert all(names[-1] == b for b, names in segs[:-1])
+        assert segs[-1][1][:2] == ["in_conv.weight", "in_conv.bias"]
+        assert all(k in segs[-1][1] for k in dict(model.named_parameters()) if k.startswith(("time_embed", "class_embed")) or ".norm" in k)

@@ -87,3 +87,55 @@ def test_two_rank_gradient_reducer():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _ddp_chain_worker(rank, world, port, q):
+    """the reference's own wrap (train.py:141-148: DDP(model)) around a network that returns the chain of autograd nodes: DDP's
+    reducer must be handed every segment's bucket BEFORE the next segment's kernels are launched, and average over ranks"""
+    try:
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "v-diffusion-torch_amd"), os.path.join(ROOT, "tests")]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        from chain_stub import ChainStub
+        S = 200_000                                           # every parameter > 1 MiB: one DDP bucket each (bucket_cap_mb=1)
+        m = ChainStub(scale=S)
+        ddp = DDP(m, bucket_cap_mb=1)
+
+        def hook(state, bucket):
+            m.log.append("bucket " + "+".join(k for k, p in m.named_parameters() if any(p is q_ for q_ in bucket.parameters())))
+            return default_hooks.allreduce_hook(state, bucket)
+        ddp.register_comm_hook(None, hook)
+        for it in range(3):                                  # (iteration 0: DDP puts everything in ONE bucket, then rebuilds them in arrival order)
+            m.log.clear()
+            ddp.zero_grad(set_to_none=True)
+            (ddp(torch.ones(2, 3)).sum() * (rank + 1)).backward()
+            log = [e for e in m.log if e != "closed"]
+            want = ["kernels c", "bucket c", "kernels b-part", "kernels b", "bucket b", "kernels a", "bucket a"]
+            if it == 0:
+                want = [e for e in want if e.startswith("kernels")] + ["bucket a+b+c"]
+            assert log == want, (it, log)
+            mean_s = sum(6.0 * (r + 1) for r in range(world)) / world          # dout.sum() = 6 (r + 1) on rank r
+            assert torch.allclose(m.c.grad, torch.full((4 * S,), 1 * mean_s)) and torch.allclose(m.b.grad, torch.full((2 * S,), 2 * mean_s))
+            assert torch.allclose(m.a.grad, torch.full((3 * S,), 3 * mean_s))
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:      # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_two_rank_ddp_wrap_overlaps_through_the_autograd_chain():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_chain_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

@@ -418,6 +418,10 @@ GROUPED_AUTO_SPLIT = os.environ.get("VD_GROUPED_AUTO_SPLIT", "1") != "0"
 # UNet-level boundaries only (0: fewer, larger grouped weight-gradient launches; buckets leave in bursts)
 GN_FOLD = os.environ.get("VD_GN_FOLD", "1") != "0"       # A/B switch: 0 = statistics finalize and apply as two launches
 READY_PER_BLOCK = os.environ.get("VD_READY_PER_BLOCK", "0") != "0"
+# a training forward outside the flat-buffer trainer returns a CHAIN of autograd nodes cut at the engine's progress points, so that the
+# reference's own DDP(model) (train.py:141-148) sees gradients -- and launches its bucket all-reduces -- while backward still runs
+# (models/unet.py::_SegFn); 0 = one node for the whole network (A/B switch: same kernels, same results bit for bit, no overlap)
+AUTOGRAD_CHAIN = os.environ.get("VD_AUTOGRAD_CHAIN", "1") != "0"
 WINO43_WGRAD = os.environ.get("VD_WINO43_WGRAD", "1") != "0"   # A/B switch: 0 keeps every weight gradient on F(2x2,3x3)
 # fewest 4x4-output tiles (= K of the 36 GEMMs) it is picked for: 512 = 8x8 images at batch 128 (256 -> 256: x1.17, 768 -> 768: x1.41 over the fused
 # F(2x2,3x3) kernel, same-box A/B tests/perf_wgrad43.py); the library serves nothing below 512

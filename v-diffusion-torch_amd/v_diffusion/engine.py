@@ -141,6 +141,8 @@ class UNetEngine:
         self._pgb_arena = self._pgb_table = None
         self._side = self._side_stream = None     # side stream of the 3x3 weight gradients (VD_WGRAD_STREAM)
         self._wq = None                   # {shape key: [(dY, X, dW, dbias)]} of deferred weight-gradient GEMMs (inside backward only)
+        self._active_run = None           # the chain-of-nodes backward pass in flight (models/unet.py::_BackwardRun), one at a time
+        self._segments = None
 
     # ------------------------------------------------------------------------------------------ small helpers
     @staticmethod
@@ -848,20 +850,98 @@ class UNetEngine:
         return {k: torch.empty_like(p) for k, p in self.m.named_parameters()}
 
     def backward(self, tape, dout, G, need_dx=False, progress=None):
-        """see _backward; the deferred weight-gradient queue and the side stream never outlive the call, whatever it raises"""
+        """Fills ``G`` (name -> tensor, every entry overwritten) and returns d/dx (NCHW) when asked.  ``progress(name)`` is called whenever
+        the gradient of ``name`` and of everything before it in completion_order() is final (gradient-bucket overlap).  The deferred
+        weight-gradient queue and the side stream never outlive the call, whatever it raises (backward_steps' ``finally``)."""
+        steps = self.backward_steps(tape, dout, G, need_dx, join=progress is not None)
         try:
-            return self._backward(tape, dout, G, need_dx, progress)
+            while True:
+                name = next(steps)
+                if progress is not None:
+                    progress(name)
+        except StopIteration as fin:
+            return fin.value
+
+    def progress_points(self):
+        """The names ``backward_steps`` yields, in order (static: a function of the plan): the output convolution, the last block of every
+        (UNet level, down / middle / up) group -- of every block under VD_READY_PER_BLOCK when a listener joins -- the input convolution,
+        and None for the end of backward (GroupNorm parameters and the embeddings finish there)."""
+        pts = ["out_conv.2.bias"]
+        grp = lambda q: (q.level, "mid" if q.kind.startswith("mid") else q.kind)
+        for bi in range(len(self.plan) - 1, -1, -1):
+            b = self.plan[bi]
+            nxt = self.plan[bi - 1] if bi > 0 else None
+            if nxt is None or grp(nxt) != grp(b):
+                pts.append(b.prefix + ".proj_in.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
+        return pts + ["in_conv.bias", None]
+
+    def grad_segments(self):
+        """[(boundary name, [parameter names])] in BACKWARD order: segment j's gradients are final when ``backward_steps`` yields its
+        boundary; the last segment (input convolution, every GroupNorm scale / shift, the embeddings) is final when the pass ends
+        (boundary None).  The cut points of the chain of autograd nodes of models/unet.py."""
+        if self._segments is None:
+            bounds = [p for p in self.progress_points() if p not in ("in_conv.bias", None)] + [None]
+            order, segs, i = self.completion_order(), [], 0
+            for bnd in bounds:
+                names = []
+                while i < len(order):
+                    names.append(order[i])
+                    i += 1
+                    if order[i - 1] == bnd:
+                        break
+                segs.append((bnd, names))
+            assert i == len(order) and all(n for _, n in segs)
+            self._segments = segs
+        return self._segments
+
+    def completion_order(self):
+        """Parameter names in the order ``backward_steps`` finishes their gradients: block by block from the output back (the
+        matmul-shaped gradients, i.e. all the bytes), then the GroupNorm scales / shifts of the whole network (their per-image terms
+        are summed by one launch at the end of backward: _pgb_finish), then the embeddings."""
+        names = ["out_conv.2.weight", "out_conv.2.bias"]
+        norms = ["out_conv.0.weight", "out_conv.0.bias"]
+        have = dict(self.m.named_parameters())
+
+        def res(p):
+            out = [p + s for s in (".conv2.weight", ".conv2.bias", ".conv1.weight", ".conv1.bias")]
+            norms.extend(p + s for s in (".norm2.weight", ".norm2.bias", ".norm1.weight", ".norm1.bias"))
+            if p + ".skip.weight" in have:
+                out += [p + ".skip.weight", p + ".skip.bias"]
+            return out + [p + ".fc.weight", p + ".fc.bias"]
+
+        def att(p):
+            norms.extend(p + s for s in (".norm.weight", ".norm.bias"))
+            return [p + s for s in (".proj_out.weight", ".proj_out.bias", ".proj_in.weight", ".proj_in.bias")]
+
+        for b in reversed(self.plan):
+            if b.kind == "midattn":
+                names += att(b.prefix)
+            elif b.att is not None:
+                names += att(b.prefix + ".1") + res(b.prefix + ".0")
+            else:
+                names += res(b.prefix)
+        names += ["in_conv.weight", "in_conv.bias"] + norms
+        seen = set(names)
+        names += [k for k in have if k not in seen]          # embeddings: finished last
+        assert sorted(names) == sorted(have), "completion order does not cover the parameter set"
+        return names
+
+    def backward_steps(self, tape, dout, G, need_dx=False, join=True):
+        """Generator form of the backward pass: runs up to the next point at which a prefix of completion_order() is final, yields the
+        last finished name (progress_points() lists them), and returns d/dx through StopIteration.  ``join``: a listener consumes the
+        gradients at every yield (a gradient reducer, or autograd handing a segment's gradients to DDP's hooks: models/unet.py), so the
+        weight-gradient side stream is joined there; without one it is joined once, at the end."""
+        try:
+            dx = yield from self._backward(tape, dout, G, need_dx, join)
+            return dx
         finally:
             self._wq = None
             self._side = None
 
-    def _backward(self, tape, dout, G, need_dx=False, progress=None):
-        """dout: NHWC ``[B,H,W,Cp]`` gradient of the padded output (padding channels zero).  Fills ``G`` (name -> tensor,
-        every entry overwritten) and returns d/dx (NCHW) when asked.  ``progress(name)`` is called whenever the gradient
-        of ``name`` and of everything before it in trainer.completion_order() is final (gradient-bucket overlap)."""
+    def _backward(self, tape, dout, G, need_dx=False, join=False):
+        """dout: NHWC ``[B,H,W,Cp]`` gradient of the padded output (padding channels zero)."""
         m = self.m
-        self._join_at_progress = progress is not None          # a gradient reducer is listening: finished means finished on every stream
-        progress = progress or (lambda name: None)
+        self._join_at_progress = bool(join)                    # a listener consumes gradients at every yield: finished means finished on every stream
         B, H0, W0, cop, _ = _chk(dout)
         self._wino = tape.get("wino", getattr(self, "_wino", None))     # the Winograd images THIS forward packed (another forward may have run since)
         ta = tape["ta"]
@@ -900,7 +980,7 @@ class UNetEngine:
                        False, None, None, None, False, B, H0, W0, C0, GROUPS,
                        pgb_keep=self._pgb(B, C0, G["out_conv.0.weight"], G["out_conv.0.bias"]))
         del da
-        progress("out_conv.2.bias")            # (the GroupNorm parameter gradients are finished by ONE launch at the end: _pgb_finish)
+        yield "out_conv.2.bias"                # (the GroupNorm parameter gradients are finished by ONE launch at the end: _pgb_finish)
         # ---- blocks in reverse
         dskip = {}                     # hs id -> gradient view (written by the consuming up-block)
         dh_cur = dh                    # gradient of the running `h`
@@ -939,7 +1019,7 @@ class UNetEngine:
                 self._wgrad_flush()
                 if self._join_at_progress:
                     self._side_join()
-                progress(b.prefix + ".proj_in.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
+                yield (b.prefix + ".proj_in.bias" if b.kind == "midattn" else (b.prefix + (".0" if b.att is not None else "") + ".fc.bias"))
             if b.kind == "up" and b.consumes:
                 dh_cur = dxbuf[..., :b.ch_h]
                 dskip[b.src_hs] = dxbuf[..., b.ch_h:]
@@ -958,7 +1038,7 @@ class UNetEngine:
         else:
             H.conv3x3_wgrad(tape["in"]["x4"], cip, dy0, _ld(dy0), B, H0, W0, cip, hid, G["in_conv.weight"], m.in_channels, hid,
                             dbias=G["in_conv.bias"])
-        progress("in_conv.bias")
+        yield "in_conv.bias"
         dx = None
         if need_dx:
             d4 = self._new(dout, B, H0, W0, cip)
@@ -975,7 +1055,7 @@ class UNetEngine:
         self._side_join()
         self._side = None
         self._wq = None
-        progress(None)
+        yield None
         return dx
 
     def _hs_feeding(self, bi):

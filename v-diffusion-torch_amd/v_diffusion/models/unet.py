@@ -46,9 +46,10 @@ class ResidualBlock(nn.Module):
 
 
 class _UNetFn(torch.autograd.Function):
-    """One autograd node for the whole network: forward runs the engine and keeps its tape, backward runs the engine's
-    hand-written backward and hands one gradient per parameter to autograd (so DDP hooks, ``.grad`` accumulation and
-    optimizers behave as with the reference)."""
+    """One autograd node for the whole network -- the form the flat-buffer trainer uses (``trainer.FlatState``: the kernels write into
+    the caller's flat gradient buffer and ``GradReducer`` listens to the engine's progress itself), and the A/B form of the chain below
+    (``VD_AUTOGRAD_CHAIN=0``).  Forward runs the engine and keeps its tape, backward runs the engine's hand-written backward and hands
+    one gradient per parameter to autograd."""
 
     @staticmethod
     def forward(ctx, model, x, t, y, *params):
@@ -65,13 +66,10 @@ class _UNetFn(torch.autograd.Function):
             raise RuntimeError("UNet backward called twice (the tape is freed after the first backward)")
         ctx.tape = None
         eng = model.engine()
-        B, co, Hh, Ww = dout.shape
-        cop = (co + 3) // 4 * 4
         flat = model._flat_grad_views is not None
         G = model._grad_targets()
         with torch.cuda.device(dout.device):
-            d4 = torch.empty((B, Hh, Ww, cop), dtype=torch.float32, device=dout.device)
-            _hip.nchw_to_nhwc(dout.to(torch.float32).contiguous(), d4, B, co, Hh, Ww, cop)
+            d4 = model._dout_nhwc(dout)
             dx = eng.backward(tape, d4, G, need_dx=ctx.need_dx, progress=getattr(model, "_grads_ready_hook", None))
         if flat:
             # the kernels already wrote into the caller's flat gradient buffer (trainer.FlatState): autograd gets nothing
@@ -82,6 +80,108 @@ class _UNetFn(torch.autograd.Function):
         no_labels = bool(model.num_classes) and tape["embed"]["yn"] is None
         return (None, dx, None, None) + tuple(None if (no_labels and k.startswith("class_embed.")) else G[k]
                                               for k, _ in model.named_parameters())
+
+
+class _BackwardRun:
+    """What one forward shares with its chain of ``_SegFn`` nodes: the tape, then the running backward pass (the engine's generator),
+    the gradient tensors not yet handed to autograd, and d/dx."""
+
+    def __init__(self, model, tape, need_dx, segs, device):
+        self.model, self.tape, self.need_dx, self.segs, self.device = model, tape, need_dx, segs, device
+        self.out = self.gen = self.G = self.dx = None
+        self.no_labels = False
+        self.reached = -1                  # index (backward order) of the last segment whose gradients are final
+        self.finished = False
+
+    def start(self, dout):
+        if self.tape is None:
+            raise RuntimeError("UNet backward called twice (the tape is freed after the first backward)")
+        tape, self.tape = self.tape, None
+        self.gen, self.G, self.no_labels = self.model._chain_begin(self, tape, dout, self.need_dx)
+
+    def advance(self, j):
+        """run the backward pass until the gradients of segment ``j`` are final (the last segment: until it ends)"""
+        last = len(self.segs) - 1
+        try:
+            while self.reached < j:
+                try:
+                    name = next(self.gen)
+                except StopIteration as fin:
+                    self.dx, self.reached = fin.value, last
+                    self._end()
+                    break
+                bound = self.segs[self.reached + 1][0]
+                if bound is not None and name == bound:
+                    self.reached += 1
+        except BaseException:
+            self._end()
+            raise
+
+    def take(self, j):
+        """segment j's gradients, in the order of its parameter list; the run lets go of them (autograd's AccumulateGrad keeps a
+        gradient tensor nobody else holds instead of cloning it)"""
+        G, skip = self.G, self.no_labels
+        return [None if (skip and k.startswith("class_embed.")) else G.pop(k) for k in self.segs[j][1]]
+
+    def drain(self):
+        """finish the pass now (another backward of the same engine is about to start: the engine's queue / side-stream / arena state
+        belongs to one pass at a time); the remaining nodes find their gradients in G"""
+        if not self.finished and self.gen is not None:
+            self.advance(len(self.segs) - 1)
+
+    def stop_early(self):
+        """nothing upstream of the current node takes part in this backward (frozen parameters, input without gradient): end the pass
+        at the yield it stands at (the side stream is joined at every yield of a listening pass)"""
+        if self.gen is not None:
+            self.gen.close()
+        self._end()
+
+    def _end(self):
+        self.finished, self.gen = True, None
+        self.model._chain_end(self)
+
+
+class _SegFn(torch.autograd.Function):
+    """One node of the CHAIN of autograd nodes a training forward returns (SURVEY section 5 option (1); reference train.py:141-148 wraps
+    the model in DDP and train_utils.py:154 relies on DDP's hooks firing as gradients become ready).  The network is cut at the engine's
+    progress points (engine.grad_segments: the output convolution, every UNet level of the up / middle / down path, the rest); node j
+    owns the parameters of segment j and is linked to node j+1 through a one-element token, so autograd runs the nodes strictly in
+    backward order.  Each node resumes the engine's backward pass (a generator) until its segment's gradients are final and returns
+    them: their AccumulateGrad nodes -- and with them DDP's per-parameter hooks and bucket all-reduces -- run BEFORE the next node
+    launches the next level's kernels, which is how the reference's own ``DDP(model)`` overlaps communication with backward here.
+    The kernels, their order and their results are those of the single-node form, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, run, j, carrier, *params):
+        ctx.run, ctx.j = run, j
+        if j == 0:                          # the node backward starts from returns the network's output
+            out, run.out = run.out, None
+            return out
+        return carrier.new_empty((1,), dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        run, j = ctx.run, ctx.j
+        with torch.cuda.device(run.device) if run.device.type == "cuda" else _nullctx():
+            if j == 0:
+                run.start(g)
+            run.advance(j)
+            grads = run.take(j)
+            if j == len(run.segs) - 1:
+                cg = run.dx
+            else:
+                cg = run.model._chain_token(run.device)
+                if not ctx.needs_input_grad[2]:
+                    run.stop_early()
+        return (None, None, cg) + tuple(grads)
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 class UNet(nn.Module):
@@ -152,6 +252,7 @@ class UNet(nn.Module):
         self._engine = None
         self._flat_grad_views = None
         self._grads_ready_hook = None
+        self._tokens = {}
 
     # ------------------------------------------------------------------ engine plumbing
     def engine(self):
@@ -165,6 +266,51 @@ class UNet(nn.Module):
         if self._flat_grad_views is not None:
             return self._flat_grad_views
         return {k: torch.empty_like(p) for k, p in self.named_parameters()}
+
+    def _dout_nhwc(self, dout):
+        """NCHW output gradient -> the engine's NHWC layout, channels padded to a multiple of 4 (padding never read as data)"""
+        B, co, Hh, Ww = dout.shape
+        cop = (co + 3) // 4 * 4
+        d4 = torch.empty((B, Hh, Ww, cop), dtype=torch.float32, device=dout.device)
+        _hip.nchw_to_nhwc(dout.to(torch.float32).contiguous(), d4, B, co, Hh, Ww, cop)
+        return d4
+
+    # ---- chain of autograd nodes (see _SegFn)
+    def _chain_begin(self, run, tape, dout, need_dx):
+        eng = self.engine()
+        other = eng._active_run
+        if other is not None and other is not run:
+            other.drain()
+        G = self._grad_targets()
+        no_labels = bool(self.num_classes) and tape["embed"]["yn"] is None
+        gen = eng.backward_steps(tape, self._dout_nhwc(dout), G, need_dx=need_dx, join=True)
+        eng._active_run = run
+        return gen, G, no_labels
+
+    def _chain_end(self, run):
+        eng = self._engine
+        if eng is not None and eng._active_run is run:
+            eng._active_run = None
+
+    def _chain_token(self, device):
+        tok = self._tokens.get(device)
+        if tok is None:
+            tok = self._tokens[device] = torch.zeros((1,), dtype=torch.float32, device=device)
+        return tok
+
+    def _forward_chain(self, x, t, y):
+        eng = self.engine()
+        with torch.no_grad(), torch.cuda.device(x.device):
+            out, tape = eng.forward(x, t, y, self.training, save=True)
+            out = self._to_nchw(out)
+        segs = eng.grad_segments()
+        named = dict(self.named_parameters())
+        run = _BackwardRun(self, tape, x.requires_grad, segs, x.device)
+        run.out = out
+        carrier = x
+        for j in range(len(segs) - 1, -1, -1):         # forward order: the segment backward finishes LAST is the first node
+            carrier = _SegFn.apply(run, j, carrier, *[named[k] for k in segs[j][1]])
+        return carrier
 
     def _to_nchw(self, out_nhwc):
         B, Hh, Ww, cop = out_nhwc.shape
@@ -181,6 +327,8 @@ class UNet(nn.Module):
             return x.new_zeros((0, self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32)
         params = list(self.parameters())
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            if self._flat_grad_views is None and _hip.AUTOGRAD_CHAIN:
+                return self._forward_chain(x, t, y)
             return _UNetFn.apply(self, x, t, y, *params)
         with torch.cuda.device(x.device):
             out, _ = self.engine().forward(x, t, y, self.training, save=False)

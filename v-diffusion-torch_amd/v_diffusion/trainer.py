@@ -34,37 +34,8 @@ RESERVE_CUS_DP = 0
 
 
 def completion_order(model):
-    """Parameter names in the order ``UNetEngine.backward`` finishes their gradients: block by block from the output back (the
-    matmul-shaped gradients, i.e. all the bytes), then the GroupNorm scales / shifts of the whole network (their per-image terms
-    are summed by one launch at the end of backward: engine._pgb_finish), then the embeddings."""
-    eng = model.engine()
-    names = ["out_conv.2.weight", "out_conv.2.bias"]
-    norms = ["out_conv.0.weight", "out_conv.0.bias"]
-    have = dict(model.named_parameters())
-
-    def res(p):
-        out = [p + s for s in (".conv2.weight", ".conv2.bias", ".conv1.weight", ".conv1.bias")]
-        norms.extend(p + s for s in (".norm2.weight", ".norm2.bias", ".norm1.weight", ".norm1.bias"))
-        if p + ".skip.weight" in have:
-            out += [p + ".skip.weight", p + ".skip.bias"]
-        return out + [p + ".fc.weight", p + ".fc.bias"]
-
-    def att(p):
-        norms.extend(p + s for s in (".norm.weight", ".norm.bias"))
-        return [p + s for s in (".proj_out.weight", ".proj_out.bias", ".proj_in.weight", ".proj_in.bias")]
-
-    for b in reversed(eng.plan):
-        if b.kind == "midattn":
-            names += att(b.prefix)
-        elif b.att is not None:
-            names += att(b.prefix + ".1") + res(b.prefix + ".0")
-        else:
-            names += res(b.prefix)
-    names += ["in_conv.weight", "in_conv.bias"] + norms
-    rest = [k for k in have if k not in set(names)]          # embeddings: finished last
-    names += rest
-    assert sorted(names) == sorted(have), "completion order does not cover the parameter set"
-    return names
+    """Parameter names in the order ``UNetEngine.backward`` finishes their gradients (engine.completion_order)."""
+    return model.engine().completion_order()
 
 
 class FlatState:
