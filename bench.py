@@ -118,6 +118,61 @@ def cpu_baseline(wl="cifar10", batch=16, budget_s=18.0):
                       f"torch CPU fp32 on {ncpu} threads, {model_name}"}
 
 
+def torch_rocm_baseline(wl="cifar10", batch=128, steps=3, warmup=2, device="cuda"):
+    """BASELINE LEG ONLY (after the timed region, like cpu_baseline; never a target, never in the product path): the same train-step
+    math -- q_sample + UNet forward + snr_trunc v-loss + backward, no optimizer -- through STOCK PyTorch-ROCm on the same MI355X: the
+    oracle's functional restatement (oracle/unet_ref.py, proved equal to the reference by the goldens) moved to the device, i.e. ATen
+    convolutions on MIOpen, rocBLAS / hipBLASLt GEMMs, autograd backward; fp32 with TF32-class paths off (train.py:233-237 resolves
+    allow_tf32=False on a non-NVIDIA device name).  It stands in for the number BASELINE.json.published lacks ("reference-GPU
+    images/sec"): what the reference's own code achieves on this GPU.  Batch 128 (64 on an out-of-memory error)."""
+    from oracle import unet_ref, diffusion_ref as dref
+    from oracle.unet_ref import param_shapes
+    W = WORKLOADS[wl]
+    cfg, res = W["cfg"], W["res"]
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cudnn.benchmark = True                         # (train.py:237 sets it: MIOpen picks its fastest solver per shape)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in param_shapes(cfg).items():
+        fan = max(int(torch.tensor(shp[1:]).prod()) if len(shp) > 1 else 1, 1)
+        sd[k] = (torch.randn(shp, generator=g) * fan ** -0.5).to(device).requires_grad_(True)
+    sched = dref.make_schedule("cosine")
+    den = lambda a, b, c: unet_ref.unet_forward(sd, cfg, a, b, c, train=True)
+    B = batch
+    while True:
+        try:
+            x0 = (torch.rand((B, 3, res, res), generator=g) * 2 - 1).to(device)
+            if cfg.get("multitags"):
+                y = (torch.rand((B, cfg["num_classes"]), generator=g) < 0.2).float().to(device)
+            else:
+                y = torch.randint(1, cfg["num_classes"] + 1, (B,), generator=g).float().to(device)
+            times = []
+            for i in range(warmup + steps):
+                t = torch.rand((B,), dtype=torch.float64, generator=g).to(device)
+                noise = torch.randn(x0.shape, generator=g).to(device)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loss = dref.train_loss(den, sched, x0, t, y, noise, "v", "snr_trunc").mean()
+                loss.backward()
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                for v in sd.values():
+                    v.grad = None
+            break
+        except torch.OutOfMemoryError:
+            if B <= 16:
+                raise
+            B //= 2
+            torch.cuda.empty_cache()
+    timed = sorted(times[warmup:])
+    med = timed[len(timed) // 2]
+    return {"value": round(B / med, 2), "unit": "images/s", "kind": "port on ATen/MIOpen", "baseline_only": True,
+            "ms_per_step": round(med * 1e3, 2), "batch": B, "finite": bool(torch.isfinite(loss)),
+            "sample": f"{W['short']} train step WITHOUT optimizer (q_sample+fwd+v-loss+autograd bwd), batch {B}, median of {steps} steps "
+                      f"after {warmup} warm-ups, stock torch {torch.__version__} fp32 (TF32 off, MIOpen benchmark mode), same GPU"}
+
+
 # fwd_exec_frac: share of the ALGORITHMIC forward FLOPs the matrix cores execute -- FALLBACK ONLY (non-zero ranks, which record no launches):
 # the sampling roofline takes the share from the launches two reverse steps of the run record (sample_once).  These constants are the
 # all-F(2x2,3x3) values: CIFAR (32.61 * 4/9 + 0.03 + 5.00) / 37.64; CelebA (183.71 * 4/9 + 0.09 + 17.50) / 201.3
@@ -203,7 +258,7 @@ def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, ba
             "finite": bool(torch.isfinite(out).all())}
 
 
-def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_steps, extras=True):
+def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_steps, extras=True, uint8_input=False):
     """build the workload's model + trainer, time `steps` train steps, then the live per-kernel roofline of two more"""
     import v_diffusion
     from v_diffusion import _hip
@@ -234,7 +289,15 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
     else:
         labels = torch.randint(1, 11, (B,), device=device, generator=g).float()            # target_transform y+1
 
+    if uint8_input:
+        # --uint8-input: the batch as the dataset holds it before the reference's CPU transforms (datasets.py:111-126): uint8 HWC + flip
+        # decisions, resident in HBM; every step starts with vd_images_from_uint8_hwc (flip + ToTensor + Normalize on the device)
+        u8 = torch.randint(0, 256, (B, RES, RES, 3), device=device, generator=g, dtype=torch.uint8)
+        flips = torch.rand((B,), device=device, generator=g) < 0.5
+
     def one_step():
+        if uint8_input:
+            return trainer.step_uint8(u8, labels.clone(), flip=flips)
         return trainer.step(x, labels.clone())          # y is mutated by the label drop: hand over a fresh copy
 
     for _ in range(warmup):
@@ -403,6 +466,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the CelebA (BASELINE configs[3]) secondary block")
     ap.add_argument("--no-extras", action="store_true", help="skip the loss.item() / fwd+bwd-only variants (profiling runs: keeps the "
                     "launch count at warmup + steps + 2 train steps)")
+    ap.add_argument("--uint8-input", action="store_true", help="feed every train step a uint8 HWC batch + flip mask (the dataset's format "
+                    "before the reference's CPU transforms, datasets.py:111-126) through HotPathTrainer.step_uint8")
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm baseline leg (torch_rocm_baseline)")
     ap.add_argument("--sample-steps", type=int, default=50)
     ap.add_argument("--config", choices=["cifar10", "celeba"], default="cifar10",
                     help="cifar10 = the headline workload (BASELINE configs[1]); celeba = configs[3] as the primary line")
@@ -420,7 +486,7 @@ def main():
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: the gloo side channel (a host flag per update) needs no hostname lookup
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: a gloo backend (VD_BENCH_BACKEND=gloo dry runs) needs no hostname lookup
         backend = os.environ.get("VD_BENCH_BACKEND", "nccl")                                  # "nccl" == RCCL on ROCm
         opts = None
         if backend == "nccl" and os.environ.get("VD_RCCL_HIGH_PRIORITY", "0") != "0":
@@ -442,7 +508,8 @@ def main():
         torch.cuda.synchronize()
 
     B = args.batch
-    r = run_training(wl, B, args.steps, args.warmup, device, rank, world, barrier, args.sample_steps, extras=not args.no_extras)
+    r = run_training(wl, B, args.steps, args.warmup, device, rank, world, barrier, args.sample_steps, extras=not args.no_extras,
+                     uint8_input=args.uint8_input)
     model, diffusion, labels, RES = r["model"], r["diffusion"], r["labels"], r["res"]
     fwd_gflop = r["fwd_gflop"]
     hbm_peak = torch.cuda.max_memory_allocated(device)
@@ -494,6 +561,19 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    # the same math through stock PyTorch-ROCm on this GPU (baseline leg only, after every timed region; rank 0 at N = 1 like cpu_baseline)
+    torch_base = None
+    if rank == 0 and world == 1 and not args.no_torch_baseline:
+        import gc
+        r.pop("trainer", None); r.pop("model", None); r.pop("diffusion", None)
+        model = diffusion = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            torch_base = torch_rocm_baseline(wl, batch=B, device=device)
+            torch_base["hot_path_over_baseline"] = round(r["value"] / torch_base["value"], 3)
+        except Exception as e:                      # a baseline that cannot run must not take the measured line down with it
+            torch_base = {"value": None, "kind": "port on ATen/MIOpen", "baseline_only": True, "error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         line = {"metric": "train_images_per_sec", "value": round(r["value"], 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -505,7 +585,8 @@ def main():
                            "final_loss": round(r["final_loss"], 5)},
                 "ms_per_step_with_loss_item": r.get("ms_per_step_with_loss_item"), "ms_fwd_bwd_only": r.get("ms_fwd_bwd_only"),
                 "hbm_peak_gib": round(hbm_peak / 2 ** 30, 2),
-                "roofline": r["roofline"], "cpu_baseline": cpu, "sampling": sampling, "multi_gpu": r.get("multi_gpu"),
+                "roofline": r["roofline"], "cpu_baseline": cpu, "torch_rocm_baseline": torch_base, "sampling": sampling,
+                "multi_gpu": r.get("multi_gpu"), "input": "uint8 HWC + flip mask -> vd_images_from_uint8_hwc" if args.uint8_input else "fp32 NCHW",
                 "secondary": secondary}
         print(json.dumps(line), flush=True)
     if dist.is_initialized():

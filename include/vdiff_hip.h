@@ -397,6 +397,16 @@ int vd_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64
                  const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
                  float bc1, float bc2, float ema_decay, int64_t r_lo, int64_t r_hi, int32_t r_mode, float r_bc1, float r_bc2,
                  void* stream);
+/* the same update with the decision about [r_lo, r_hi) made ON THE DEVICE: r_flag[0] > 0 (device float: "some rank's micro-batch of
+ * this update carried labels" -- one slot behind the flat gradient buffer, summed over ranks by the last gradient bucket's
+ * all-reduce) -> the range is updated with the bias corrections of step count r_steps[0] + 1 (1 - r_beta^k, evaluated in double on
+ * the device) and r_steps[0] is advanced; else the range is skipped as r_mode 1 does.  No host ever reads the flag: replaces the
+ * per-update host all-reduce the reference's DDP + torch.optim.AdamW pair needs no equivalent of (train_utils.py:159-163:
+ * optimizer.step() skips parameters whose .grad is None; under DDP that is the same on every rank by construction). */
+int vd_adamw_ema_flagged(float* p, const float* g, float* m, float* v, float* ema, int64_t n,
+                         const float* gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                         float bc1, float bc2, float ema_decay, int64_t r_lo, int64_t r_hi, const float* r_flag, int32_t* r_steps,
+                         double r_beta1, double r_beta2, void* stream);
 
 #ifdef __cplusplus
 }

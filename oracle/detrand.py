@@ -53,6 +53,22 @@ def randint(name: str, shape, lo: int, hi: int, seed: int = 0) -> torch.Tensor:
     return (u * (hi - lo)).floor().long() + lo
 
 
+def signs(name: str, n: int, seed: int = 0) -> torch.Tensor:
+    """n values of +-1 (float64): the sign pattern of one random projection (gradient digests of the full-size goldens)"""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + _key(name, seed)
+    h = _splitmix64(idx)
+    return torch.from_numpy(1.0 - 2.0 * ((h >> np.uint64(40)) & np.uint64(1)).astype(np.float64))
+
+
+def projections(name: str, g: torch.Tensor, k: int = 4) -> np.ndarray:
+    """k deterministic +-1 projections of a tensor, float64: sum_i s_j(i) g_i for the sign patterns ("proj<j>:" + name).  Unlike a norm
+    they see the position and the sign of every element: a permuted, transposed or sign-flipped block moves them by the size of that
+    block."""
+    v = g.detach().double().flatten().cpu()
+    return np.array([float((signs(f"proj{j}:{name}", v.numel()) * v).sum()) for j in range(k)])
+
+
 def fill_state_dict(shapes: dict, seed: int = 0) -> dict:
     """Random-looking weights for every tensor of a UNet state_dict.
 

@@ -36,8 +36,10 @@ def import_reference():
 
 
 def grad_digest(named_grads):
-    """Per-tensor L2 norm + first 16 elements (keeps fixtures small)."""
-    norms, heads, names = [], [], []
+    """Per-tensor L2 norm + first 16 elements + four +-1 projections over the WHOLE tensor (keeps fixtures small; the projections
+    catch what norm + leading elements cannot: a permutation, transposition or sign error deep inside a tensor)."""
+    from oracle import detrand
+    norms, heads, names, projs = [], [], [], []
     for n, g in named_grads:
         g = g.detach().double().flatten()
         names.append(n)
@@ -46,7 +48,8 @@ def grad_digest(named_grads):
         k = min(16, g.numel())
         h[:k] = g[:k].numpy()
         heads.append(h)
-    return np.array(names), np.array(norms), np.stack(heads)
+        projs.append(detrand.projections(n, g))
+    return np.array(names), np.array(norms), np.stack(heads), np.stack(projs)
 
 
 def check(name, a, b, atol, rtol=0.0):
@@ -61,6 +64,7 @@ def check(name, a, b, atol, rtol=0.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-celeba", action="store_true")
+    ap.add_argument("--only-unet", action="store_true", help="rewrite tests/golden/unet_*.npz only (the other fixtures are untouched)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -102,9 +106,9 @@ def main():
         check("dx", xo.grad, xr.grad, 1e-6, 1e-5)
         for (k, g) in ref_grads:
             check("d" + k, sdo[k].grad, g, 1e-7, 2e-5)
-        names, norms, heads = grad_digest(ref_grads)
+        names, norms, heads, projs = grad_digest(ref_grads)
         np.savez_compressed(os.path.join(GOLD, f"unet_{name}.npz"), out=out.detach().numpy(), dx=xr.grad.numpy(),
-                            grad_names=names, grad_norms=norms, grad_heads=heads)
+                            grad_names=names, grad_norms=norms, grad_heads=heads, grad_projs=projs)
 
     # ------------------------------------------------------------------ (ii) full-size UNets
     big = [("cifar10_cond", CIFAR_COND, 2, 32, "single")]
@@ -132,10 +136,14 @@ def main():
             worst = max(worst, rel)
         print(f"  worst grad rel-L2 oracle vs ref: {worst:.3e}")
         assert worst < 1e-4
-        names, norms, heads = grad_digest(ref_grads)
+        names, norms, heads, projs = grad_digest(ref_grads)
         np.savez_compressed(os.path.join(GOLD, f"unet_{name}.npz"), out=out.detach().numpy(), nparam=nparam,
-                            grad_names=names, grad_norms=norms, grad_heads=heads)
+                            grad_names=names, grad_norms=norms, grad_heads=heads, grad_projs=projs)
         del m, sd, sdo
+
+    if args.only_unet:
+        print("unet goldens written to", GOLD)
+        return
 
     # ------------------------------------------------------------------ (iv) embedding / schedule / posterior tables
     print("== tables")
@@ -199,8 +207,8 @@ def main():
     gd = RefGD(ref_get_schedule("cosine", -20.0, 20.0), 8, "v", "fixed_large", "snr_trunc", "mse", p_uncond=0.0)
     loss = gd.train_loss(m, x0, t.clone(), y.clone(), noise)
     loss.mean().backward()
-    names, norms, heads = grad_digest([(k, p.grad) for k, p in m.named_parameters()])
-    np.savez_compressed(os.path.join(GOLD, "train_loss.npz"), grad_names=names, grad_norms=norms, grad_heads=heads,
+    names, norms, heads, projs = grad_digest([(k, p.grad) for k, p in m.named_parameters()])
+    np.savez_compressed(os.path.join(GOLD, "train_loss.npz"), grad_names=names, grad_norms=norms, grad_heads=heads, grad_projs=projs,
                         **{"loss_" + k: v for k, v in losses.items()})
 
     # ------------------------------------------------------------------ (vi) sampling trajectories (explicit noises)

@@ -194,7 +194,8 @@ def attn_block(x, sd, p, head_dim, num_heads):
 
 def embed(sd, cfg, t, y):
     cfg = normalize_cfg(cfg)
-    te = timestep_embedding(t, cfg["hid_channels"])
+    # (fp32 as in the reference; a float64 state_dict -- the tests' fp32-vs-fp64 spread measurements -- gets the embedding in its dtype)
+    te = timestep_embedding(t, cfg["hid_channels"], out_dtype=sd["time_embed.0.weight"].dtype)
     te = F.linear(te, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     te = F.linear(F.silu(te), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
     if cfg["num_classes"] and y is not None:

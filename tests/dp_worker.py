@@ -24,7 +24,7 @@ def fixed_batch(cfg, B, R, steps):
     return out
 
 
-def run(rank, world, B, steps, dev="cuda"):
+def run(rank, world, B, steps, dev="cuda", accum=1):
     import v_diffusion
     from v_diffusion.trainer import HotPathTrainer
     from oracle.cases import CIFAR_COND, make_weights
@@ -34,14 +34,19 @@ def run(rank, world, B, steps, dev="cuda"):
     model.to(dev).train()
     gd = v_diffusion.GaussianDiffusion(v_diffusion.get_logsnr_schedule("cosine", -20.0, 20.0), 50, "v", "fixed_medium", "snr_trunc",
                                        "mse", intp_frac=0.3, w_guide=1.0, p_uncond=0.0)
-    tr = HotPathTrainer(model, gd, lr=2e-4, warmup=0, grad_norm=1.0, use_ema=True, rank=rank, world_size=world)
+    tr = HotPathTrainer(model, gd, lr=2e-4, warmup=0, grad_norm=1.0, use_ema=True, rank=rank, world_size=world, num_accum=accum)
     p0 = tr.flat.p.detach().cpu().clone()
     per = B // world
-    rows = slice(rank * per, (rank + 1) * per)
+    mb = per // accum
     losses, g1 = [], None
     for s, (x0, t, y, noise) in enumerate(fixed_batch(cfg, B, 32, steps)):
-        loss = tr.step(x0[rows].to(dev), y[rows].to(dev), t=t[rows].to(dev), noise=noise[rows].to(dev))
-        losses.append(float(loss))
+        # --num-accum (train.py:292, train_utils.py:154,257): the rank's rows in `accum` micro-batches, loss / accum each, gradients summed,
+        # the optimizer runs with the last one
+        part = []
+        for a in range(accum):
+            rows = slice(rank * per + a * mb, rank * per + (a + 1) * mb)
+            part.append(tr.step(x0[rows].to(dev), y[rows].to(dev), update=a == accum - 1, t=t[rows].to(dev), noise=noise[rows].to(dev)))
+        losses.append(float(sum(part) / accum))
         if s == 0:
             g1 = tr.flat.g.detach().cpu().clone()
     torch.cuda.synchronize()
@@ -54,11 +59,12 @@ if __name__ == "__main__":
     ap.add_argument("--out", required=True)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--accum", type=int, default=1)
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = run(rank, world, a.batch, a.steps)
+    res = run(rank, world, a.batch, a.steps, accum=a.accum)
     # every rank must hold the same replica after the update (DDP invariant)
     ref = res["p"].clone().cuda()
     dist.broadcast(ref, src=0)

@@ -100,6 +100,38 @@ def test_two_ranks_equal_one_rank_on_the_full_batch(tmp_path):
         assert abs(a - b) <= 2e-6 * max(abs(b), 1.0), (two["losses"], one["losses"])
 
 
+def test_num_accum_microbatches_equal_one_batch(tmp_path):
+    """--num-accum (reference train.py:292; train_utils.py:154 ``loss.div(num_accum).backward()``, :257 ``step(..., update=(i + 1) %
+    num_accum == 0)``): HotPathTrainer(num_accum=2) fed two micro-batches of B/2 rows -- the flat gradient buffer kept as a running
+    sum, clip + AdamW + EMA with the second -- must land on the parameters / EMA shadow of num_accum=1 on the B rows at once, for one
+    rank and for two data-parallel ranks (each rank's 8 rows in two micro-batches of 4; gradient buckets all-reduced per micro-batch as
+    DDP does without no_sync).  Same tolerances as test_two_ranks_equal_one_rank_on_the_full_batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import dp_worker
+    one = dp_worker.run(0, 1, 16, 2)
+    acc = dp_worker.run(0, 1, 16, 2, accum=2)
+    out = str(tmp_path / "dp2acc.pt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29557", os.path.join(ROOT, "tests", "dp_worker.py"), "--out", out, "--batch", "16", "--steps", "2",
+           "--accum", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    two = torch.load(out)
+    assert two["replicas_identical"], "the two replicas diverged"
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    for tag, got in (("1 rank x 2 micro-batches of 8", acc), ("2 ranks x 2 micro-batches of 4", two)):
+        eg, ep, ee = rel(got["g1"], one["g1"]), rel(got["p"], one["p"]), rel(got["ema"], one["ema"])
+        ed = rel(got["p"].double() - got["p0"].double(), one["p"].double() - one["p0"].double())
+        print(f"{tag} vs 1 x 16 rows: gradient rel-L2 {eg:.2e}, parameters {ep:.2e}, EMA {ee:.2e}, displacement {ed:.2e}; "
+              f"losses {got['losses']} vs {one['losses']}")
+        assert eg <= 1e-6 and ep <= 1e-6 and ee <= 1e-6 and ed <= 1e-3
+        for a, b in zip(got["losses"], one["losses"]):
+            assert abs(a - b) <= 2e-6 * max(abs(b), 1.0), (got["losses"], one["losses"])
+
+
 def test_two_rank_rccl_launch_when_two_gpus_are_visible():
     """The same launch line over RCCL, one rank per GPU -- runs wherever the box has at least two devices (the build's own boxes
     have one: skipped there; the driver's multi-GPU node exercises it without further work).  Checks the contract line AND the

@@ -26,6 +26,11 @@ def _digest_check(g, grads, rtol=2e-5, head_atol=1e-6, floor=0.0):
         assert abs(float(gr.norm()) - ref_norm) <= rtol * max(ref_norm, 1e-12) + fl, n
         k = min(16, gr.numel())
         np.testing.assert_allclose(gr[:k].numpy(), g["grad_heads"][i][:k], rtol=1e-4, atol=head_atol * max(ref_norm, 1e-6) + fl, err_msg=n)
+        if "grad_projs" in g.files:
+            # four +-1 projections over the whole tensor (oracle/detrand.py::projections): position and sign of every element.  A random
+            # projection of an error vector e is ~ |e|_2, so 4x the norm tolerance keeps the same rel-L2 statement
+            pr = detrand.projections(n, gr)
+            assert np.abs(pr - g["grad_projs"][i]).max() <= 4 * (rtol * max(ref_norm, 1e-12) + fl), (n, pr, g["grad_projs"][i])
 
 
 @pytest.mark.parametrize("name", list(TINY))

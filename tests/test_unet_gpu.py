@@ -38,7 +38,8 @@ def _build(vd, cfg, train=False):
 def _check_grads(g, model, rel=1e-4):
     names = [str(n) for n in g["grad_names"]]
     assert names == [k for k, _ in model.named_parameters()]
-    worst = 0.0
+    from oracle import detrand
+    worst = worst_proj = 0.0
     # tensors whose exact gradient is zero (a conv bias in front of a GroupNorm with one channel per group) hold
     # pure rounding noise in the reference too: compare them on the scale of the largest gradient, not their own
     floor = 1e-6 * float(np.max(g["grad_norms"]))
@@ -51,6 +52,13 @@ def _check_grads(g, model, rel=1e-4):
         worst = max(worst, nerr / max(ref_norm, floor / rel))
         assert nerr <= rel * ref_norm + floor, f"{k}: |grad| {float(gr.norm()):.6e} vs reference {ref_norm:.6e}"
         assert head_err <= max(2e-4, rel) * ref_norm + floor, f"{k}: leading elements differ by {head_err:.3e} (norm {ref_norm:.3e})"
+        # four +-1 projections over the WHOLE tensor (oracle/detrand.py::projections; fixtures regenerated from the reference in round
+        # 5): a permutation, transposition or sign error anywhere in the tensor moves them by the size of the affected block, which
+        # norm + leading elements cannot see.  A random projection of an error vector e is ~ |e|_2: 4x the rel-L2 bound.
+        perr = np.abs(detrand.projections(k, gr) - g["grad_projs"][i]).max()
+        worst_proj = max(worst_proj, perr / max(ref_norm, floor / rel))
+        assert perr <= 4 * (rel * ref_norm + floor), f"{k}: +-1 projections differ by {perr:.3e} (norm {ref_norm:.3e})"
+    print(f"worst gradient-norm error {worst:.2e}, worst projection error {worst_proj:.2e} (of the tensor's norm)")
     return worst
 
 
@@ -841,3 +849,41 @@ def test_async_uint8_sample_export(vd):
         got = p.numpy()
         assert got.dtype == np.uint8 and got.shape == want.shape and p.tensor().is_pinned() and p.ready()
         assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1      # (round-to-nearest vs truncation at .5 ties)
+
+
+def test_step_uint8_consumes_the_dataset_format(vd):
+    """SURVEY 8f row 3 (reference datasets.py:111-126: RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5) on DataLoader workers):
+    HotPathTrainer.step_uint8 takes the batch as the dataset holds it -- uint8 HWC + the flip decisions -- and must make exactly the
+    update ``step`` makes on the batch those transforms produce (torch formula below), with the same injected t / noise: loss,
+    parameters and EMA shadow bit for bit over two updates."""
+    from oracle.cases import TINY
+    from v_diffusion.trainer import HotPathTrainer
+    case = TINY["tinyA"]
+    cfg, R = case["cfg"], case["R"]
+    gd = vd.GaussianDiffusion(vd.get_logsnr_schedule("cosine"), 8, "v", "fixed_large", "snr_trunc", "mse", p_uncond=0.0)
+    g = torch.Generator().manual_seed(11)
+    B = 6
+    u8 = torch.randint(0, 256, (B, R, R, 3), generator=g, dtype=torch.uint8)
+    flip = torch.tensor([1, 0, 0, 1, 1, 0], dtype=torch.bool)
+    y = torch.tensor([1.0, 4.0, 10.0, 2.0, 7.0, 3.0])
+    tt = torch.rand((2, B), generator=g, dtype=torch.float64)
+    nz = torch.randn((2, B, 3, R, R), generator=g)
+    xt = u8.permute(0, 3, 1, 2).float() / 255.0                                   # ToTensor
+    xt = torch.where(flip[:, None, None, None], xt.flip(-1), xt)                  # RandomHorizontalFlip (commutes with ToTensor)
+    x_ref = ((xt - 0.5) / 0.5).to(DEV)                                            # Normalize(0.5, 0.5)
+    out = []
+    for use_u8 in (False, True):
+        model, _ = _build(vd, cfg, train=True)
+        tr = HotPathTrainer(model, gd, lr=1e-3, warmup=2, grad_norm=1.0, ema_decay=0.9, use_ema=True)
+        losses = []
+        for s in range(2):
+            kw = dict(t=tt[s].to(DEV), noise=nz[s].to(DEV))
+            if use_u8:
+                losses.append(tr.step_uint8(u8.to(DEV), y.to(DEV).clone(), flip=flip.to(DEV), **kw))
+            else:
+                losses.append(tr.step(x_ref, y.to(DEV).clone(), **kw))
+        torch.cuda.synchronize()
+        out.append((torch.stack(losses).cpu(), tr.flat.p.detach().cpu().clone(), tr.flat.ema.detach().cpu().clone()))
+    (l0, p0, e0), (l1, p1, e1) = out
+    assert torch.equal(l0, l1) and torch.equal(p0, p1) and torch.equal(e0, e1)
+    assert torch.isfinite(l0).all() and float(l0.min()) > 0

@@ -34,6 +34,11 @@ __global__ void sumsq_final_kernel(const float* part, int nb, float* out) {
 //             and torch.optim.AdamW skips the parameter -- no moment decay, no weight decay, no update, step not advanced);
 //             p, m, v stay untouched, the EMA shadow still follows p (utils.py:144-149 walks every parameter);
 //   r_mode 2: the range is updated with its own bias corrections r_bc1 / r_bc2 (its per-parameter step count lags the rest).
+//   r_mode 3: decided ON THE DEVICE (vd_adamw_ema_flagged): r_flag[0] > 0 -> as r_mode 2 with the bias corrections of step count
+//             r_steps[0] + 1 (1 - beta^k evaluated here in double), else as r_mode 1; cls_step_advance_kernel then advances r_steps[0].
+//             In data-parallel runs the flag is one extra slot behind the flat gradient buffer, summed over ranks by the LAST bucket's
+//             all-reduce (trainer.FlatState): whether the class embedding received a gradient is one decision for all replicas, made
+//             without a collective of its own and without any host reading it.
 // every operand of the update is streamed once: non-temporal accesses (VD_OPT_NT=0: plain; same-box A/B tests/probe/r04_pass15.sh:
 // 404-409 vs 439-442 us for the 243 MB CIFAR buffers, 5.4 vs 5.0 TB/s)
 #ifndef VD_OPT_NT
@@ -55,7 +60,18 @@ __device__ __forceinline__ void st1(float* p, float v) {
 }
 __global__ void adamw_ema_kernel(float* p, const float* g, float* m, float* v, float* ema, long long n, const float* gnorm_sq,
                                  float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                 float ema_decay, long long r_lo, long long r_hi, int r_mode, float r_bc1, float r_bc2) {
+                                 float ema_decay, long long r_lo, long long r_hi, int r_mode, float r_bc1, float r_bc2,
+                                 const float* r_flag, const int* r_steps, double r_beta1, double r_beta2) {
+    if (r_mode == 3) {
+        if (r_flag[0] > 0.f) {
+            const double kc = (double)(r_steps[0] + 1);
+            r_bc1 = (float)(1.0 - pow(r_beta1, kc));
+            r_bc2 = (float)(1.0 - pow(r_beta2, kc));
+            r_mode = 2;
+        } else {
+            r_mode = 1;
+        }
+    }
     float clip = 1.f;
     if (gnorm_sq && max_norm > 0.f) {
         const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);          // torch clip_grad_norm_
@@ -76,6 +92,10 @@ __global__ void adamw_ema_kernel(float* p, const float* g, float* m, float* v, f
         }
         if (ema) { const float e = ld1(ema + i); st1(ema + i, e + (1.f - ema_decay) * (pi - e)); }
     }
+}
+
+__global__ void cls_step_advance_kernel(const float* r_flag, int* r_steps) {
+    if (r_flag[0] > 0.f) r_steps[0] += 1;
 }
 
 constexpr int SUMSQ_BLOCKS = 1024;
@@ -103,7 +123,25 @@ extern "C" int vd_adamw_ema(float* p, const float* g, float* m, float* v, float*
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (long long)n,
                        gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay, (long long)r_lo, (long long)r_hi, (int)r_mode,
-                       r_mode == 2 ? r_bc1 : 1.f, r_mode == 2 ? r_bc2 : 1.f);
+                       r_mode == 2 ? r_bc1 : 1.f, r_mode == 2 ? r_bc2 : 1.f, (const float*)nullptr, (const int*)nullptr, 0.0, 0.0);
     VD_LAUNCH_CHECK("adamw_ema_kernel");
+    return 0;
+}
+
+extern "C" int vd_adamw_ema_flagged(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gnorm_sq,
+                                    float max_norm, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                    float ema_decay, int64_t r_lo, int64_t r_hi, const float* r_flag, int32_t* r_steps,
+                                    double r_beta1, double r_beta2, void* stream) {
+    VD_REQUIRE(r_flag && r_steps, "vd_adamw_ema_flagged: needs the device flag and the device step counter");
+    VD_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n, "vd_adamw_ema_flagged: bad range [%lld, %lld)", (long long)r_lo, (long long)r_hi);
+    VD_REQUIRE(r_beta1 >= 0.0 && r_beta1 < 1.0 && r_beta2 >= 0.0 && r_beta2 < 1.0, "vd_adamw_ema_flagged: betas must lie in [0, 1)");
+    long long grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (long long)n,
+                       gnorm_sq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay, (long long)r_lo, (long long)r_hi, 3,
+                       1.f, 1.f, r_flag, (const int*)r_steps, r_beta1, r_beta2);
+    VD_LAUNCH_CHECK("adamw_ema_kernel");
+    hipLaunchKernelGGL(cls_step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, r_flag, (int*)r_steps);
+    VD_LAUNCH_CHECK("cls_step_advance_kernel");
     return 0;
 }

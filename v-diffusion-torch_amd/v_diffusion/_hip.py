@@ -120,6 +120,8 @@ _SIGNATURES = {
     "vd_sumsq": (C.c_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "vd_adamw_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _i64, _i32,
                                _f32, _f32, _vp]),
+    "vd_adamw_ema_flagged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _i64,
+                                       _vp, _vp, _f64, _f64, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 # extra entry points of libvdiff_hip_probe.so (built with -DVD_PROBES; tests/probe/*.py load it through VDIFF_HIP_LIB): bound when
@@ -163,7 +165,7 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise HipError("v_diffusion HIP op received a CPU tensor: the hot path runs on an MI355X only (no CPU fallback)")
-    if t.dtype not in (torch.float32, torch.float64, torch.uint8):
+    if t.dtype not in (torch.float32, torch.float64, torch.uint8, torch.int32):
         raise HipError(f"unsupported dtype {t.dtype}")
     return t.data_ptr()
 
@@ -737,3 +739,12 @@ def adamw_ema(p, g, m, v, ema, gnorm_sq, max_norm, lr, b1, b2, eps, wd, bc1, bc2
     """r_*: an index range treated apart this step, see vd_adamw_ema (1 = no gradient this step, 2 = own bias corrections)"""
     _check(lib().vd_adamw_ema(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), ptr(gnorm_sq), max_norm, lr, b1, b2, eps,
                               wd, bc1, bc2, ema_decay, int(r_lo), int(r_hi), int(r_mode), r_bc1, r_bc2, stream()), "vd_adamw_ema")
+
+
+def adamw_ema_flagged(p, g, m, v, ema, gnorm_sq, max_norm, lr, b1, b2, eps, wd, bc1, bc2, ema_decay, r_lo, r_hi, r_flag, r_steps):
+    """the update with the [r_lo, r_hi) decision made on the device (vd_adamw_ema_flagged): r_flag = device float[1], r_steps = device
+    int32[1] (advanced by the call when the flag is set)"""
+    assert r_flag.dtype == torch.float32 and r_steps.dtype == torch.int32
+    _check(lib().vd_adamw_ema_flagged(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), ptr(gnorm_sq), max_norm, lr, b1, b2, eps,
+                                      wd, bc1, bc2, ema_decay, int(r_lo), int(r_hi), ptr(r_flag), ptr(r_steps), float(b1), float(b2),
+                                      stream()), "vd_adamw_ema_flagged")

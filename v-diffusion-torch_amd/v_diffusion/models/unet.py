@@ -110,6 +110,9 @@ class _BackwardRun:
                     self.dx, self.reached = fin.value, last
                     self._end()
                     break
+                hook = getattr(self.model, "_grads_ready_hook", None)
+                if hook is not None:
+                    hook(name)              # (the engine's progress report, as in the single-node form)
                 bound = self.segs[self.reached + 1][0]
                 if bound is not None and name == bound:
                     self.reached += 1

@@ -27,6 +27,7 @@ import torch.distributed as dist
 from . import _hip
 
 BUCKET_BYTES = 32 << 20
+FLAG_SLOTS = 4            # floats behind the flat gradient buffer that travel with its last bucket (16 bytes: keeps buckets float4-sized)
 # CUs the persistent convolution kernels leave to RCCL in data-parallel runs unless VD_RESERVE_CUS says otherwise.  0: measured on one MI355X
 # (1-rank RCCL, reducer on) reserving 8 CUs costs 6 % of the step -- the dominant kernel's 2048 work items need a ninth
 # round on 248 CUs -- while an unreserved bucket waits at most one persistent launch (< 0.8 ms) and only the last bucket's wait is exposed.
@@ -52,7 +53,11 @@ class FlatState:
             n += (params[k].numel() + 3) // 4 * 4                      # keep every tensor 16-byte aligned
         self.numel, self.offsets, self.order = n, offs, order
         self.p = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        # gradients + FLAG_SLOTS floats behind them: slot 0 says "this rank's micro-batch carried labels" (see cls_range below); it rides
+        # in the last gradient bucket, so the rank SUM of the all-reduce makes it one decision for all replicas at no extra collective
+        self.g_all = torch.zeros(n + FLAG_SLOTS, dtype=torch.float32, device=dev)
+        self.g = self.g_all[:n]
+        self.flag = self.g_all[n:n + 1]
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         views = {}
@@ -81,7 +86,17 @@ class FlatState:
             assert all(lo <= offs[k] < hi for k in cls) and not any(lo <= offs[k] < hi for k in order if k not in self.cls_names), \
                 "class-embedding tensors are not contiguous in the flat buffer"
             self.cls_range = (lo, min(hi, n))
-        self.cls_steps = 0
+        self.cls_steps_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # advanced by vd_adamw_ema_flagged, never read per step
+
+    @property
+    def cls_steps(self):
+        """updates in which the class embedding received a gradient (its torch.optim.AdamW per-parameter step): lives on the device;
+        reading it synchronises (checkpoints only)"""
+        return int(self.cls_steps_dev.item())
+
+    @cls_steps.setter
+    def cls_steps(self, k):
+        self.cls_steps_dev.fill_(int(k))
 
     def ema_state_dict(self):
         """EMA shadow as a reference-format state_dict (utils.py:168-175 keeps ``shadow`` per parameter name)."""
@@ -95,7 +110,8 @@ class GradReducer:
     def __init__(self, flat: FlatState, world_size, bucket_bytes=BUCKET_BYTES, group=None, force=False):
         self.flat, self.world, self.group = flat, world_size, group
         self.active = world_size > 1 or force        # force: run the collectives even on one rank (tests)
-        n, per = flat.numel, max(bucket_bytes // 4, 1)
+        n, per = flat.g_all.numel(), max(bucket_bytes // 4, 1)        # (the flag slots behind the gradients ride in the last bucket)
+        self.total = n
         self.bounds = [(a, min(a + per, n)) for a in range(0, n, per)]
         # first flat offset AFTER each parameter, in completion order -> "ready prefix" length
         params = dict(flat.model.named_parameters())
@@ -111,7 +127,7 @@ class GradReducer:
             self.trace = [ev]
 
     def _launch(self, lo, hi):
-        t = self.flat.g[lo:hi]
+        t = self.flat.g_all[lo:hi]
         if self.trace is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()                            # on the compute stream: the point of backward at which this bucket's gradients were final
@@ -131,7 +147,7 @@ class GradReducer:
         """Called by the backward pass when ``name`` (and everything before it in completion order) is final."""
         if not self.active:
             return
-        upto = self.flat.numel if name is None else self.end_of[name]
+        upto = self.total if name is None else self.end_of[name]
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][1] <= upto:
             self._launch(*self.bounds[self.next_bucket])
             self.next_bucket += 1
@@ -222,7 +238,6 @@ class HotPathTrainer:
         # the leader = first member of the process group (global rank 0 need not belong to a sub-group)
         self.leader = dist.get_global_rank(group, 0) if (world_size > 1 and group is not None) else 0
         self.is_leader = world_size == 1 or (dist.get_rank() == self.leader if dist.is_initialized() else rank == 0)
-        self._flag_group = None
         if world_size > 1 and os.environ.get("VD_RESERVE_CUS") is None and RESERVE_CUS_DP:
             # RCCL's kernels must find a CU while the persistent convolution kernels hold theirs for a whole launch (one workgroup per
             # CU, all of its LDS): leave RESERVE_CUS_DP of them out of those grids (vd_set_reserved_cus; 1-GPU cost in DESIGN section 4)
@@ -231,17 +246,6 @@ class HotPathTrainer:
             dist.broadcast(self.flat.p, src=self.leader, group=group)
             if self.flat.ema is not None:
                 self.flat.ema.copy_(self.flat.p)
-            if self.flat.cls_range is not None:
-                # whether the class embedding received a gradient in an update must be ONE decision for all replicas (the gradients are
-                # averaged over ranks; a rank-local decision would let replicas that saw y = None skip an update the others apply).  The
-                # flag travels as a host integer over a gloo group: no device synchronisation on the step's critical path.
-                ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-                try:
-                    self._flag_group = dist.new_group(ranks=ranks, backend="gloo")
-                except Exception as e:       # no usable gloo transport on this node: the flag travels through the gradient group instead
-                    import warnings
-                    warnings.warn(f"gloo flag group unavailable ({e}); the class-embedding flag is reduced on the device (one host sync per update)")
-                    self._flag_group = "device"
 
     def draw(self, x):
         B = x.shape[0]
@@ -259,20 +263,24 @@ class HotPathTrainer:
         flat = self.flat
         if t is None or noise is None:
             t, noise = self.draw(x)
-        if y is not None:
-            self._cls_grad = True                                  # some micro-batch of this update reached the class embedding
+        if flat.cls_range is not None:
+            # did this micro-batch reach the class embedding?  One float behind the gradients: it is summed over ranks with the last
+            # gradient bucket (and over micro-batches with the accumulation buffer), and vd_adamw_ema_flagged reads it on the device --
+            # whether the class embedding is updated is ONE decision for all replicas (the gradients are averaged over ranks; a
+            # rank-local decision would let replicas that saw y = None skip an update the others apply), and no host waits for another
+            flat.flag.fill_(0.0 if y is None else 1.0)
         loss = self.diffusion.train_loss(self.model, x_0=x, t=t, y=y, noise=noise).mean()
         self.reducer.start()
         self.model._grads_ready_hook = self.reducer.ready if self.reducer.active else None     # (no listener: backward joins its side stream once, at the end)
         (loss / (self.num_accum * self.world)).backward()          # 1/world folds DDP's gradient averaging into the seed
         self.model._grads_ready_hook = None
         self.reducer.finish()
-        if self.num_accum > 1:                                     # the engine overwrites flat.g: keep the running sum
-            if getattr(self, "_acc", None) is None:
-                self._acc = torch.zeros_like(flat.g)
-            self._acc.add_(flat.g)
+        if self.num_accum > 1:                                     # the engine overwrites flat.g: keep the running sum (train_utils.py:154,
+            if getattr(self, "_acc", None) is None:                # :257 -- loss / num_accum, .grad accumulated over the micro-batches)
+                self._acc = torch.zeros_like(flat.g_all)
+            self._acc.add_(flat.g_all)
             if update:
-                flat.g.copy_(self._acc)
+                flat.g_all.copy_(self._acc)
                 self._acc.zero_()
         if update:
             flat.step_count += 1
@@ -283,36 +291,29 @@ class HotPathTrainer:
             if flat.ema is not None:
                 flat.ema_updates += 1
                 decay = min(self.ema_decay, (1 + flat.ema_updates) / (10 + flat.ema_updates))   # utils.py:145-146
-            rng = {}
+            args = (flat.p, flat.g, flat.m, flat.v, flat.ema, flat.gnorm_sq, float(self.grad_norm), lr, self.betas[0], self.betas[1],
+                    self.eps, self.wd, 1 - self.betas[0] ** k, 1 - self.betas[1] ** k, decay)
             if flat.cls_range is not None:
                 # reference semantics of parameters without a gradient (torch.optim.AdamW skips them: no moment decay, no weight
-                # decay, no update, their own step counter): see vd_adamw_ema
-                cls_grad = bool(getattr(self, "_cls_grad", False))
-                if self._flag_group == "device":
-                    f = torch.tensor([int(cls_grad)], dtype=torch.int32, device=self.device)
-                    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.reducer.group)
-                    cls_grad = bool(f.item())
-                elif self._flag_group is not None:                 # any rank had labels -> every rank applies the averaged gradient
-                    f = torch.tensor([int(cls_grad)], dtype=torch.int32)
-                    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self._flag_group)
-                    cls_grad = bool(f.item())
-                if not cls_grad:
-                    rng = dict(r_lo=flat.cls_range[0], r_hi=flat.cls_range[1], r_mode=1)
-                else:
-                    flat.cls_steps += 1
-                    if flat.cls_steps != k:
-                        kc = flat.cls_steps
-                        rng = dict(r_lo=flat.cls_range[0], r_hi=flat.cls_range[1], r_mode=2, r_bc1=1 - self.betas[0] ** kc,
-                                   r_bc2=1 - self.betas[1] ** kc)
-            self._cls_grad = False
-            _hip.adamw_ema(flat.p, flat.g, flat.m, flat.v, flat.ema, flat.gnorm_sq, float(self.grad_norm), lr, self.betas[0],
-                           self.betas[1], self.eps, self.wd, 1 - self.betas[0] ** k, 1 - self.betas[1] ** k, decay, **rng)
+                # decay, no update, their own step counter), decided and counted on the device: see vd_adamw_ema_flagged
+                _hip.adamw_ema_flagged(*args, flat.cls_range[0], flat.cls_range[1], flat.flag, flat.cls_steps_dev)
+            else:
+                _hip.adamw_ema(*args)
         loss = loss.detach()
         if self.world > 1:                                         # train_utils.py:156-158: the leader reports the rank mean
             dist.reduce(loss, dst=self.leader, op=dist.ReduceOp.SUM, group=self.reducer.group)
             loss.div_(self.world)
         self.stats.update(x.shape[0], loss=loss * x.shape[0])      # train_utils.py:169, without its .item()
         return loss
+
+    def step_uint8(self, u8_hwc, y, flip=None, **kw):
+        """``step`` on a batch as the dataset holds it BEFORE the reference's CPU transforms (datasets.py:111-126: PIL image ->
+        RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5), run by the DataLoader workers in float): ``u8_hwc`` (B, H, W, C) uint8
+        on the device, ``flip`` (B,) bool / uint8 or None (the flip decisions; drawn by the loader, data not model state).  One launch
+        (vd_images_from_uint8_hwc) produces the normalised fp32 NCHW batch q_sample and the loss read: the host ships a quarter of the
+        bytes and does no float work -- what keeps 8 GPUs at > 10 k img/s fed without 8 x 4 transform workers."""
+        from .functions import from_uint8_images
+        return self.step(from_uint8_images(u8_hwc, flip), y, **kw)
 
     @property
     def current_stats(self):                                       # train_utils.py:305-307
