@@ -163,6 +163,11 @@ int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, v
 /* all tensors in one launch: items_dev = [n][8] int64 {w, U43, fwd, Cout, Cin, 0, 0, first block}; fwd = 0: the input-gradient image,
  * (Cin/32)*(Cout/8) blocks; fwd = 1: the forward image of vd_wino43_pack_fwd, (Cout/32)*(Cin/8) blocks */
 int vd_wino43_pack_batched(const int64_t* items_dev, int32_t n, int64_t total_blocks, void* stream);
+/* occupancy rule between the two Winograd orders: 1 when the F(4x4,3x3) convolution kernel (forward: N = Cout; input gradient: N = Cin) is
+ * expected to beat the F(2x2,3x3) one on this batch -- both run persistent work items in rounds over the CUs, F(2x2,3x3) has four times as
+ * many at 3/8 of the time each (measured at B = 128), so with fewer items than CUs (small-batch sampling) the finer items win.  The
+ * engine asks this next to the *_supported queries; the kernels themselves serve every supported geometry regardless. */
+int vd_conv3x3_wino43_preferred(int32_t nimg, int32_t H, int32_t W, int32_t N);
 /* ---- FORWARD pass of the same convolution through F(4x4,3x3) (replaces F.conv2d of modules.py:141-144 for the residual-block
  * convolutions unet.py:121,125 on the 16x16 / 32x32 / 64-wide layers), with the interpolation points {0, +-3/4, +-3/2, inf}: every
  * coefficient of the data and output transforms is a dyadic rational, exact in fp32, and the whole-network output error is ~2x that of

@@ -101,6 +101,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #ifndef VD_W43_DPS
 #define VD_W43_DPS 1          /* DMA pieces of tile kt+2 issued per step behind the barrier */
 #endif
+// start-up skew of the persistent workgroups: equal work items keep all 256 CUs in phase, so every item boundary is one chip-wide burst
+// of residual reads and output writes (FINDINGS round 4: the residual costs 15 % of a forward launch).  Workgroup w of an XCD sleeps
+// ((w >> 3) % NPH) * SLEEPS * ~3.7 us before its first item (s_sleep 127 = 8128 cycles): NPH phases that stay apart for the whole launch.
+// static priority for the second-dispatched half of the workgroup (waves 4-7 lose VALU arbitration to the older half on every segment:
+// MI355X_MICROARCH.md "Two waves per SIMD" item 4): ONE s_setprio 1 before the item loop, no per-cluster flips.  0 = off
+#ifndef VD_W43_PRIO
+#define VD_W43_PRIO 0
+#endif
+#ifndef VD_W43_SKEW_NPH
+#define VD_W43_SKEW_NPH 4
+#endif
+#ifndef VD_W43_SKEW_SLEEPS
+#define VD_W43_SKEW_SLEEPS 0
+#endif
 // DY: the dyadic point set {0, +-3/4, +-3/2, inf} of the forward pass (the rows of bt6 below) instead of the classic {0, +-1, +-2, inf}
 template <int HALF, bool DY, typename T>
 __device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
@@ -328,6 +342,11 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
         };
         int cb = 0, grp = 0;
         if (QUAD) offsets(0);
+        if (VD_W43_PRIO && HALF == 1) __builtin_amdgcn_s_setprio(1);   // (run<1> is entered by waves 4-7 only: a wave-uniform branch)
+        if (VD_W43_SKEW_SLEEPS > 0 && p.nitems > G) {               // (more than one round of items: the phases meet again and again)
+            const int ph = ((int)blockIdx.x >> 3) % VD_W43_SKEW_NPH;
+            for (int i = 0; i < ph * VD_W43_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+        }
         for (int n = 0; item_of(n, cb, grp); ++n) {
             if (QUAD) xitem = p.x + (long long)grp * (4 * 16 * 16) * p.ldx;
             else { offsets(grp); xitem = p.x + (long long)(grp / p.items_per_img) * p.H * p.W * p.ldx; }
@@ -873,6 +892,20 @@ extern "C" int vd_conv3x3_dgrad_wino43_supported(int32_t nimg, int32_t H, int32_
 }
 
 extern "C" size_t vd_wino43_u_floats(int32_t Cout, int32_t Cin) { return (size_t)36 * Cout * Cin; }
+
+/* occupancy rule (round-4 advice): 1 when the F(4x4,3x3) convolution kernel is expected to beat the F(2x2,3x3) one on an (nimg, H, W) batch with
+ * N output channels (N = Cout forward, Cin for the input gradient).  Both kernels are persistent, one workgroup per CU, and run in rounds of
+ * work items: F(4x4,3x3) has nimg x (H W / 1024) x N / 32 items (16x16: nimg / 4 x N / 32), F(2x2,3x3) four times as many (64 of its 2x2 tiles
+ * cover a quarter of the pixels) at 3/8 of the time each -- the ratio measured with every CU busy (256 -> 256 @32x32, B = 128: 0.48 ms in 4
+ * rounds against 0.72 ms in 16).  With fewer items than CUs the finer items win: 16 rows of a 256-channel 32x32 layer are 128 F(4x4,3x3)
+ * items on half the chip for one long round, or 512 F(2x2,3x3) items in two short ones.  Small-batch sampling is where this decides. */
+extern "C" int vd_conv3x3_wino43_preferred(int32_t nimg, int32_t H, int32_t W, int32_t N) {
+    if (nimg <= 0 || N <= 0) return 0;
+    const long long grp = W == 16 ? (nimg + 3) / 4 : (long long)nimg * (W == 64 ? H / 16 : 1);
+    const long long i43 = grp * ((N + TN - 1) / TN), ncu = vd_persistent_cus();
+    const long long r43 = (i43 + ncu - 1) / ncu, r23 = (4 * i43 + ncu - 1) / ncu;
+    return 8 * r43 < 3 * r23;
+}
 
 /* dx[nimg][H][W][Cin] = input gradient of the 3x3 convolution with kernel w[Cout][Cin][3][3] for the output gradient dy[nimg][H][W][Cout];
  * U43 = vd_wino43_pack(w).  Every element of dx[..., :Cin] is written (no accumulation). */

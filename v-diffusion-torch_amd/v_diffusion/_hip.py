@@ -58,6 +58,7 @@ _SIGNATURES = {
     "vd_conv3x3_dgrad_wino43": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vd_wino43_last_kernel": (C.c_int, []),
     "vd_conv3x3_wino43_fwd_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64]),
+    "vd_conv3x3_wino43_preferred": (C.c_int, [_i32, _i32, _i32, _i32]),
     "vd_wino43_pack_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "vd_conv3x3_wino43_fwd_chunk_rows": (C.c_int, [_i32, _i32]),
     "vd_conv3x3_wino43_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -338,9 +339,19 @@ WINO43 = os.environ.get("VD_WINO43", "1") != "0"  # A/B switch: 0 keeps the inpu
 WINO43_MIN_W = int(os.environ.get("VD_WINO43_MIN_W", "16"))   # A/B switch: 32 keeps the 16x16 layers on F(2x2,3x3)
 
 
+# occupancy rule between F(4x4,3x3) and F(2x2,3x3) (vd_conv3x3_wino43_preferred: small batches keep the finer F(2x2,3x3) items);
+# VD_WINO43_OCC=0: F(4x4,3x3) wherever served (A/B switch)
+WINO43_OCC = os.environ.get("VD_WINO43_OCC", "1") != "0"
+
+
+def wino43_preferred(nimg, H, W, N):
+    return not WINO43_OCC or bool(lib().vd_conv3x3_wino43_preferred(nimg, H, W, N))
+
+
 def wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx):
     """input gradient of a Cin -> Cout convolution on (nimg, H, W) images through F(4x4,3x3)?"""
-    return WINO and WINO43 and W >= WINO43_MIN_W and bool(lib().vd_conv3x3_dgrad_wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx))
+    return (WINO and WINO43 and W >= WINO43_MIN_W and bool(lib().vd_conv3x3_dgrad_wino43_supported(nimg, H, W, Cin, Cout, lddy, lddx))
+            and wino43_preferred(nimg, H, W, Cin))
 
 
 def wino43_pack(w, Cout, Cin, U43):
@@ -358,7 +369,8 @@ WINO43_FWD = os.environ.get("VD_WINO43_FWD", "1") != "0"
 
 
 def wino43_fwd_supported(nimg, H, W, Cin, Cout, ldx, ldy, ldres=0):
-    return WINO and WINO43_FWD and bool(lib().vd_conv3x3_wino43_fwd_supported(nimg, H, W, Cin, Cout, ldx, ldy, ldres))
+    return (WINO and WINO43_FWD and bool(lib().vd_conv3x3_wino43_fwd_supported(nimg, H, W, Cin, Cout, ldx, ldy, ldres))
+            and wino43_preferred(nimg, H, W, Cout))
 
 
 def wino43_pack_fwd(w, Cout, Cin, U43f):

@@ -159,10 +159,11 @@ class UNetEngine:
             return None                                   # tiny images: the norm computes its own statistics
         return torch.empty(H.stats_part_numel(nimg, HW, C), dtype=torch.float32, device=ref.device)
 
-    def _parts(self, part, C, HW):
-        """[(partials, channels, chunks per image)] of the launch that just wrote `part`: chunk = half the row tile of the tile engine /
-        64 rows of the F(2x2,3x3) kernels (both through vd_gemm_last_tile), or what the F(4x4,3x3) forward kernel says (_conv)"""
-        rows, self._last_chunk_rows = getattr(self, "_last_chunk_rows", None), None
+    @staticmethod
+    def _parts(part, C, HW, rows=None):
+        """[(partials, channels, chunks per image)] of the launch that just wrote `part`.  ``rows`` = pixel rows per chunk as the launch
+        that wrote it reported (what _conv returns); None: a vd_gemm launch made immediately before this call -- its chunk is half the
+        row tile it picked (vd_gemm_last_tile)"""
         if part is None:
             return None
         return [(part, C, HW // (rows or (H.last_row_tile() // 2)))]
@@ -395,16 +396,15 @@ class UNetEngine:
 
     def _conv(self, x, ldx, w, bias, y, ldy, B, Hh, Ww, Cin, Cout, dgrad=False, res=None, ldres=0, stats_part=None):
         """3x3 convolution with kernel ``w`` (forward) or its input gradient (``dgrad``: x = dy, Cin/Cout are the GEMM's):
-        Winograd F(2x2,3x3) wherever the geometry is served, the direct implicit GEMM otherwise."""
+        Winograd F(4x4,3x3) / F(2x2,3x3) wherever the geometry is served, the direct implicit GEMM otherwise.  Returns the pixel rows per
+        chunk of the GroupNorm partial sums it left in ``stats_part`` (the consuming norm needs the chunk count: _parts)."""
         wino = getattr(self, "_wino", None)
-        self._last_chunk_rows = None
         if wino is not None and not dgrad and id(w) in wino and wino[id(w)][3] is not None \
                 and H.wino43_fwd_supported(B, Hh, Ww, Cin, Cout, ldx, ldy, ldres if res is not None else 0):
             # forward pass through F(4x4,3x3) (csrc/wino43.hip, dyadic interpolation points); its GroupNorm partials come one chunk per
             # (image, work item)
             H.conv3x3_wino43_fwd(x, ldx, wino[id(w)][3], bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres, stats_part=stats_part)
-            self._last_chunk_rows = H.wino43_fwd_chunk_rows(Hh, Ww)
-            return
+            return H.wino43_fwd_chunk_rows(Hh, Ww)
         if wino is not None and dgrad and id(w) in wino and wino[id(w)][2] is not None \
                 and H.wino43_supported(B, Hh, Ww, Cout, Cin, ldx, ldy):
             # F(4x4,3x3) input gradient (csrc/wino43.hip): x = dy [.., Cin = conv Cout], y = dx [.., Cout = conv Cin].  The pack-time choice
@@ -412,22 +412,28 @@ class UNetEngine:
             # buffer) and of this geometry -- a layer it declines falls through to the F(2x2,3x3) / direct forms below.
             assert res is None and bias is None and stats_part is None
             H.conv3x3_dgrad_wino43(x, ldx, wino[id(w)][2], y, ldy, B, Hh, Ww, Cout, Cin)
-            return
+            return None
         if wino is not None and id(w) in wino and H.wino_supported(B, Hh, Ww, Cin, Cout, ldx, ldy, ldres if res is not None else 0):
             U = wino[id(w)][1 if dgrad else 0]
-            if U is None and dgrad:
-                # a layer packed for the F(4x4,3x3) input gradient whose call declined it: rotated F(2x2,3x3) image on demand
-                U = torch.empty(16, w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
-                H.wino_pack(w, w.shape[0], w.shape[1], ud=U)
-            elif U is None:
-                # ... and likewise the forward image of a layer packed for the F(4x4,3x3) forward pass
-                U = torch.empty(16, w.shape[0], w.shape[1], dtype=torch.float32, device=w.device)
-                H.wino_pack(w, w.shape[0], w.shape[1], uf=U)
-            if U is not None:
-                H.conv3x3_wino(x, ldx, U, bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres, stats_part=stats_part)
-                return
+            if U is None:
+                # a layer packed for an F(4x4,3x3) form whose call declined it (pitches of THIS call): its F(2x2,3x3) image -- rotated for
+                # the input gradient -- is made on demand, into a buffer that lives with the pack state (one allocation per weight and
+                # direction, stable address: also valid inside a captured HIP graph), and re-packed per call like every other image
+                st = self._last_pack_state
+                fb = st.setdefault("fallback_u", {}) if st is not None else {}
+                U = fb.get((id(w), dgrad))
+                if U is None:
+                    shp = (16, w.shape[1], w.shape[0]) if dgrad else (16, w.shape[0], w.shape[1])
+                    U = fb[(id(w), dgrad)] = torch.empty(shp, dtype=torch.float32, device=w.device)
+                if dgrad:
+                    H.wino_pack(w, w.shape[0], w.shape[1], ud=U)
+                else:
+                    H.wino_pack(w, w.shape[0], w.shape[1], uf=U)
+            H.conv3x3_wino(x, ldx, U, bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres, stats_part=stats_part)
+            return H.last_row_tile() // 2              # the F(2x2,3x3) kernels: one chunk per 64 output rows, reported like a 128-row tile
         H.conv3x3(x, ldx, self._pack_d(w) if dgrad else self._pack_f(w), bias, y, ldy, B, Hh, Ww, Cin, Cout, res=res, ldres=ldres,
                   stats_part=stats_part)
+        return H.last_row_tile() // 2                  # the tile engine: half its row tile
 
     def _pack_f(self, w, cin_p=None):
         if self._packed is not None and id(w) in self._packed:
@@ -585,8 +591,8 @@ class UNetEngine:
         coef1 = self._norm(x, x_parts, mod.norm1, None, 1, 0.0, 0, rs, a1, B, Hh, Ww, Cin)
         h1 = self._new(x, B, Ho, Wo, Cout)
         ph = self._part(x, B, Ho * Wo, Cout)
-        self._conv(a1, Cin, mod.conv1.weight, mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout, stats_part=ph)
-        h1_parts = self._parts(ph, Cout, Ho * Wo)
+        rows = self._conv(a1, Cin, mod.conv1.weight, mod.conv1.bias, h1, Cout, B, Ho, Wo, Cin, Cout, stats_part=ph)
+        h1_parts = self._parts(ph, Cout, Ho * Wo, rows)
         c2, fi = self.film_slot[prefix]
         film = films[c2][fi]                              # [B][2*Cout], contiguous slice of the group's batched GEMM output
         a2 = self._new(x, B, Ho, Wo, Cout)
@@ -604,9 +610,9 @@ class UNetEngine:
         else:
             sk = xs
         pd = self._part(x, B, Ho * Wo, Cout)
-        self._conv(a2, Cout, mod.conv2.weight, mod.conv2.bias, dest, _ld(dest), B, Ho, Wo, Cout, Cout, res=sk,
-                   ldres=_ld(sk), stats_part=pd)
-        out_parts = self._parts(pd, Cout, Ho * Wo)
+        rows = self._conv(a2, Cout, mod.conv2.weight, mod.conv2.bias, dest, _ld(dest), B, Ho, Wo, Cout, Cout, res=sk,
+                          ldres=_ld(sk), stats_part=pd)
+        out_parts = self._parts(pd, Cout, Ho * Wo, rows)
         if tape is not None:
             tape[prefix] = dict(x=x, coef1=coef1, a1=a1, h1=h1, coef2=coef2, a2=a2, film=film, xs=xs if has_skip else None,
                                 seed=seed, p=p_drop)
