@@ -298,7 +298,12 @@ def ref_gn_block(x, gamma, beta, film, act, resample, mask=None):
 
 GN_CASES = [  # nimg, C, H, W, film, act, resample
     (2, 64, 8, 8, False, True, 0), (3, 96, 8, 8, True, True, 0), (2, 256, 16, 16, True, True, 0), (2, 64, 8, 8, False, True, 1),
-    (2, 64, 8, 8, False, True, 2), (2, 128, 4, 4, False, False, 0), (1, 1152, 8, 8, True, True, 0), (2, 192, 32, 32, False, True, 1)]
+    (2, 64, 8, 8, False, True, 2), (2, 128, 4, 4, False, False, 0), (1, 1152, 8, 8, True, True, 0), (2, 192, 32, 32, False, True, 1),
+    # 64x64 images (round 5): an image slab is shared by four sibling workgroups that exchange their partial sums (SPLIT form of
+    # gn_bwd_fused_kernel) -- 24-channel slabs (C = 192, 96, 384: plain loads), 32-channel slabs (C = 256: non-temporal loads), unit counts
+    # that are not multiples of 8 (3 x 4, 3 x 8 ...), with and without FiLM; the 64x64 down-sampling norm keeps the two-pass form
+    (3, 192, 64, 64, True, True, 0), (3, 96, 64, 64, False, True, 0), (2, 384, 64, 64, False, False, 0), (5, 256, 64, 64, True, True, 0),
+    (2, 192, 64, 64, False, True, 1)]
 
 
 @pytest.mark.parametrize("case", GN_CASES)
@@ -340,6 +345,9 @@ def test_gn_forward_backward(H, case):
     H.gn_apply_bwd(nhwc(dy), Cc, xd, ldx, coef, gd, bd, fd, act, 0.0, 0, rs, nhwc(add), Cc, dx, Cc, True, dfilm, dgam, dbet,
                    True, nimg, Hh, Ww, Cc)
     torch.cuda.synchronize()
+    if Hh * Ww == 4096:         # which form ran: 4 siblings per (image, slab) where the geometry is served, the two-pass form (-1) for the resampling norm
+        k = H.lib().vd_gn_bwd_last_kernel()
+        assert (k // 100000000 == 4 and k % 10000 == 1024) if rs == 0 else k == -1, k
     close(from_nhwc(dx, Cc), dx64 + 1.0, dx32 + 1.0, slack=6, floor=5e-6, name="gn dx")
     close(dgam, dg64 + 1.0, dg32 + 1.0, slack=6, floor=5e-6, name="dgamma")
     close(dbet, db64 + 1.0, db32 + 1.0, slack=6, floor=5e-6, name="dbeta")
@@ -423,8 +431,10 @@ def test_plain_resample_and_backward(H, rs):
     close(from_nhwc(dx, Cc), xs.grad, xs.grad.float(), name="resample bwd")
 
 
-def test_dropout_mask_is_consistent_and_bernoulli(H):
-    nimg, Cc, Hh, Ww, p = 4, 128, 16, 16, 0.2
+@pytest.mark.parametrize("geom", [(4, 128, 16, 16), (3, 192, 64, 64)])
+def test_dropout_mask_is_consistent_and_bernoulli(H, geom):
+    """(64x64: the SPLIT single-pass backward regenerates the mask per sibling workgroup from the element index of its pixel range)"""
+    (nimg, Cc, Hh, Ww), p = geom, 0.2
     x = rnd(nimg, Cc, Hh, Ww, seed=1) + 3.0            # keep activations away from 0
     gamma, beta = torch.ones(Cc), torch.zeros(Cc)
     xd = nhwc(x)

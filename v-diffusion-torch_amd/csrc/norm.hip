@@ -542,9 +542,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const BwdApplyArgs a,
 // dy and x twice -- and the dropout mask (Philox) is regenerated once instead of twice.
 struct FusedBwdArgs {
     BwdApplyArgs a; const float* gamma; const float* beta; const float* film; float* dfilm; float* pgb; int G, CS;
+    // SPLIT form (round 5): an image slab too large for one workgroup (64x64 images) is shared by `nsplit` SIBLING workgroups, HW / nsplit
+    // pixels each; they exchange their per-channel partial sums through xbuf [unit][sibling][2][128] and meet at cnt[unit] (zeroed by the
+    // launcher).  units = nimg * C / CS, numbered image-major.
+    int nsplit; float* xbuf; unsigned* cnt;
 };
 
-template <int NPT, int TPB, bool NT = false>
+// SPLIT: the 64x64 layers (CelebA: 13.2 ms per step through the two-pass form, which reads dy and x twice).  Workgroup ids are laid out
+// so that the siblings of a unit are 8 ids apart -- dispatched within the same few dozen workgroups and, with the round-robin XCD
+// assignment, on the same XCD -- but correctness does not rest on that: the exchange uses agent-scope (sc1) stores / loads / atomics,
+// which are coherent across the XCDs' L2s, ordered by completion (s_waitcnt vmcnt(0) in front of the counter increment), NOT by
+// release / acquire fences: on this part an agent-scope release writes back the whole L2 of the XCD, in the middle of everybody's dx
+// stream (the cooperative-launch form of round 4 lost 5x that way).  In-order dispatch makes the spin safe: siblings sit next to each
+// other in the dispatch queue, and a workgroup only ever waits for ids within 24 of its own.
+template <int NPT, int TPB, bool NT = false, bool SPLIT = false>
 __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f) {
     __shared__ float red[TPB][8];
     __shared__ float chs[2][128];        // per-channel S1 (sum dz), S2 (sum dz*xhat) ; later k*S1, k*S2
@@ -554,11 +565,22 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     constexpr int NREG = (NPT == 8 && TPB == 1024) ? 4 : NPT;
     __shared__ f32x4 xl[NPT - NREG > 0 ? NPT - NREG : 1][NPT - NREG > 0 ? TPB : 1];
     const ReduceArgs& p = f.a.r;
-    const int b = blockIdx.y, c0 = blockIdx.x * f.CS, CS = f.CS, C = p.C;
-    const int vecs = CS >> 2, rows = TPB / vecs, tid = threadIdx.x;
+    const int CS = f.CS, C = p.C, tid = threadIdx.x;
+    int b = blockIdx.y, slab = blockIdx.x, sib = 0, unit = 0;
+    if (SPLIT) {
+        const int lid = blockIdx.x, q = lid >> 3;
+        sib = q % f.nsplit;
+        unit = (q / f.nsplit) * 8 + (lid & 7);
+        const int nslab = C / CS;
+        if (unit >= p.nimg * nslab) return;                  // (the unit count is padded to a multiple of 8: whole sibling sets leave)
+        b = unit / nslab; slab = unit - b * nslab;
+    }
+    const int c0 = slab * CS;
+    const int vecs = CS >> 2, rows = TPB / vecs;
     const int r = tid / vecs, v = tid - r * vecs, c4 = c0 + 4 * v;
     const bool act = r < rows;
-    const int HW = (int)p.HW;
+    const int HW = SPLIT ? (int)p.HW / f.nsplit : (int)p.HW;     // pixels THIS workgroup holds, starting at pixel `pbeg` of the image
+    const int pbeg = SPLIT ? sib * HW : 0;
     const float* cf = p.coef + (long long)b * 4 * C;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, of = {0.f, 0.f, 0.f, 0.f}, nr = sc, nm = of;
     if (act) {
@@ -584,7 +606,7 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
         if (act) {
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
-                const int pc = min(r + i * rows, HW - 1);
+                const int pc = pbeg + min(r + i * rows, HW - 1);
                 xin[i] = ld_stream<NT>(ximg + (long long)pc * p.ldx + c4);
                 dz[i] = ld_stream<NT>(dimg + (long long)pc * p.lddy + c4);
             }
@@ -594,7 +616,7 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
             const int pix = r + i * rows;
             f32x4 xh = a0 * 0.f;
             if (act && pix < HW) {
-                const unsigned long long vi = ((unsigned long long)b * p.HW + pix) * vtot + (c4 >> 2);
+                const unsigned long long vi = ((unsigned long long)b * p.HW + pbeg + pix) * vtot + (c4 >> 2);
                 dz[i] = dz_finish(p, dz[i], xin[i], sc, of, vi);
                 xh = xin[i] * nr + nm;                      // keep x_hat: all the second half needs
                 a0 += dz[i];
@@ -644,6 +666,31 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
         }
         __syncthreads();
     }
+    if (SPLIT) {
+        // this workgroup's sums cover HW / nsplit pixels: leave them for the siblings, wait for theirs, add all nsplit in sibling order
+        // (every sibling forms the same sums in the same order -- bitwise the same group terms)
+        float* mine = f.xbuf + ((long long)unit * f.nsplit + sib) * 256;
+        if (tid < 2 * CS) __hip_atomic_store(mine + (tid / CS) * 128 + (tid % CS), chs[tid / CS][tid % CS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the stores have reached the coherence point before the counter moves
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(f.cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (bounded: a sibling that never arrives -- impossible with in-order dispatch -- must not hang the device: ~1 s, then the
+            //  poisoned counter makes every later reader of this unit leave too and the results are visibly wrong, not late)
+            for (unsigned spin = 0; __hip_atomic_load(f.cnt + unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)f.nsplit; ++spin) {
+                __builtin_amdgcn_s_sleep(8);
+                if (spin > (1u << 22)) { __hip_atomic_fetch_add(f.cnt + unit, 1u << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * CS) {
+            const float* all = f.xbuf + (long long)unit * f.nsplit * 256 + (tid / CS) * 128 + (tid % CS);
+            float t = 0.f;
+            for (int k = 0; k < f.nsplit; ++k) t += __hip_atomic_load(all + k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            chs[tid / CS][tid % CS] = t;
+        }
+        __syncthreads();
+    }
     const int cg = C / f.G;
     if (tid < CS) {
         const int c = c0 + tid;
@@ -651,12 +698,16 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
         float fs = 1.f;
         if (f.film) {
             fs = 1.f + f.film[(long long)b * 2 * C + C + c];
-            f.dfilm[(long long)b * 2 * C + c] = s1;
-            f.dfilm[(long long)b * 2 * C + C + c] = f.gamma[c] * s2 + f.beta[c] * s1;
+            if (sib == 0) {
+                f.dfilm[(long long)b * 2 * C + c] = s1;
+                f.dfilm[(long long)b * 2 * C + C + c] = f.gamma[c] * s2 + f.beta[c] * s1;
+            }
         }
         const float k = f.gamma[c] * fs;
-        f.pgb[((long long)b * 2) * C + c] = fs * s2;
-        f.pgb[((long long)b * 2 + 1) * C + c] = fs * s1;
+        if (sib == 0) {
+            f.pgb[((long long)b * 2) * C + c] = fs * s2;
+            f.pgb[((long long)b * 2 + 1) * C + c] = fs * s1;
+        }
         chs[0][tid] = k * s1; chs[1][tid] = k * s2;
     }
     __syncthreads();
@@ -675,8 +726,8 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
         const float fs = f.film ? 1.f + f.film[(long long)b * 2 * C + C + c] : 1.f;
         q0[j] = nr[j] * f.gamma[c] * fs; q1[j] = nr[j] * gm[0][g]; q2[j] = nr[j] * gm[1][g];
     }
-    const float* aimg = f.a.add ? f.a.add + (long long)b * p.HW * f.a.ldadd : nullptr;
-    float* oimg = f.a.dx + (long long)b * p.HW * f.a.lddx;
+    const float* aimg = f.a.add ? f.a.add + ((long long)b * p.HW + pbeg) * f.a.ldadd : nullptr;
+    float* oimg = f.a.dx + ((long long)b * p.HW + pbeg) * f.a.lddx;
     // dx = q0 dz - q1 - x_hat q2 (in place in dz), then the skip-path gradient / the running dx, every load of a kind in flight at once
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
@@ -899,8 +950,37 @@ static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int6
             const int TPB = (HW * (CS / 4) > 2048 || (big && HW * (CS / 4) >= 1024)) ? 1024 : 256;
             const int rows = TPB / (CS / 4);
             const int npt = (int)((HW + rows - 1) / rows);
+            // larger slabs (64x64 images): nsplit sibling workgroups per (image, slab), HW / nsplit pixels each (SPLIT form of the kernel;
+            // VD_GN_SPLIT=0: the two-pass form below, A/B switch).  Not for the resampling norms (their pixel gather spans the image).
+            static const bool no_split = getenv("VD_GN_SPLIT") && atoi(getenv("VD_GN_SPLIT")) == 0;
+            if (npt > 8 && !no_split && resample == VD_RS_NONE) {
+                int nsplit = 0;
+                for (int k = 2; k <= 8; k *= 2)
+                    if (HW % k == 0 && (HW / k + (1024 / (CS / 4)) - 1) / (1024 / (CS / 4)) <= 8) { nsplit = k; break; }
+                const long long units = (long long)nimg * (C / CS), upad = (units + 7) / 8 * 8;
+                const size_t cnt_bytes = ((size_t)upad * sizeof(unsigned) + 255) / 256 * 256;
+                const size_t need = cnt_bytes + (size_t)units * nsplit * 256 * sizeof(float);
+                const size_t avail = ((size_t)nimg * p.chunks * 2 * C + (size_t)nimg * 3 * C) * sizeof(float);     // (in front of the pgb region)
+                if (nsplit && need <= avail && upad * nsplit < (1LL << 31)) {
+                    FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS, nsplit, reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cnt_bytes),
+                                      reinterpret_cast<unsigned*>(ws)};
+                    VD_REQUIRE(hipMemsetAsync(ws, 0, cnt_bytes, st) == hipSuccess, "vd_gn_apply_bwd: hipMemsetAsync of the sibling counters failed");
+                    const bool nt = CS % 32 == 0;
+                    const dim3 grid((unsigned)(upad * nsplit));
+                    g_last_gn_bwd = 8 * 10000 + 1024 + (nt ? 1000000 : 0) + 100000000 * nsplit;
+                    if (nt) hipLaunchKernelGGL((gn_bwd_fused_kernel<8, 1024, true, true>), grid, dim3(1024), 0, st, f);
+                    else hipLaunchKernelGGL((gn_bwd_fused_kernel<8, 1024, false, true>), grid, dim3(1024), 0, st, f);
+                    VD_LAUNCH_CHECK("gn_bwd_fused_kernel<split>");
+                    if (!pgb_keep) {
+                        hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
+                                           accumulate_params);
+                        VD_LAUNCH_CHECK("sum_over_images_kernel");
+                    }
+                    return 0;
+                }
+            }
             if (npt <= 8) {
-                FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS};
+                FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS, 1, nullptr, nullptr};
                 dim3 grid(C / CS, nimg);
                 if (TPB == 1024) launch_fused_bwd<1024>(npt, grid, st, f); else launch_fused_bwd<256>(npt, grid, st, f);
                 VD_LAUNCH_CHECK("gn_bwd_fused_kernel");

@@ -104,17 +104,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 // start-up skew of the persistent workgroups: equal work items keep all 256 CUs in phase, so every item boundary is one chip-wide burst
 // of residual reads and output writes (FINDINGS round 4: the residual costs 15 % of a forward launch).  Workgroup w of an XCD sleeps
 // ((w >> 3) % NPH) * SLEEPS * ~3.7 us before its first item (s_sleep 127 = 8128 cycles): NPH phases that stay apart for the whole launch.
-// static priority for the second-dispatched half of the workgroup (waves 4-7 lose VALU arbitration to the older half on every segment:
-// MI355X_MICROARCH.md "Two waves per SIMD" item 4): ONE s_setprio 1 before the item loop, no per-cluster flips.  0 = off
-#ifndef VD_W43_PRIO
-#define VD_W43_PRIO 0
-#endif
-#ifndef VD_W43_SKEW_NPH
-#define VD_W43_SKEW_NPH 4
-#endif
-#ifndef VD_W43_SKEW_SLEEPS
-#define VD_W43_SKEW_SLEEPS 0
-#endif
+// (round 5, measured and NOT kept -- tests/probe/r05_skew.sh, gpurun_out/r05_skew.txt, FINDINGS round 5: a start-up skew of the persistent
+//  workgroups, 2 / 4 / 8 phases up to 3.7 ... 26 us apart, so that the item-boundary bursts of residual reads and output writes of the 256 CUs
+//  do not coincide: 0.471-0.483 ms against 0.478 at 256 -> 256 @32x32 with residual, i.e. nothing; one static s_setprio 1 for waves 4-7:
+//  +1.5 %.  The CUs being in phase is not what the residual costs.)
 // DY: the dyadic point set {0, +-3/4, +-3/2, inf} of the forward pass (the rows of bt6 below) instead of the classic {0, +-1, +-2, inf}
 template <int HALF, bool DY, typename T>
 __device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
@@ -342,11 +335,6 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
         };
         int cb = 0, grp = 0;
         if (QUAD) offsets(0);
-        if (VD_W43_PRIO && HALF == 1) __builtin_amdgcn_s_setprio(1);   // (run<1> is entered by waves 4-7 only: a wave-uniform branch)
-        if (VD_W43_SKEW_SLEEPS > 0 && p.nitems > G) {               // (more than one round of items: the phases meet again and again)
-            const int ph = ((int)blockIdx.x >> 3) % VD_W43_SKEW_NPH;
-            for (int i = 0; i < ph * VD_W43_SKEW_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
-        }
         for (int n = 0; item_of(n, cb, grp); ++n) {
             if (QUAD) xitem = p.x + (long long)grp * (4 * 16 * 16) * p.ldx;
             else { offsets(grp); xitem = p.x + (long long)(grp / p.items_per_img) * p.H * p.W * p.ldx; }

@@ -431,6 +431,7 @@ GROUPED_AUTO_SPLIT = os.environ.get("VD_GROUPED_AUTO_SPLIT", "1") != "0"
 # data-parallel runs (a gradient reducer listens to backward): report gradients ready after every residual / attention block (1) or at
 # UNet-level boundaries only (0: fewer, larger grouped weight-gradient launches; buckets leave in bursts)
 GN_FOLD = os.environ.get("VD_GN_FOLD", "1") != "0"       # A/B switch: 0 = statistics finalize and apply as two launches
+GN_FOLD_MAX_CHUNKS = int(os.environ.get("VD_GN_FOLD_MAX_CHUNKS", "8"))     # most chunks per image the folded form re-reduces per workgroup
 READY_PER_BLOCK = os.environ.get("VD_READY_PER_BLOCK", "0") != "0"
 # a training forward outside the flat-buffer trainer returns a CHAIN of autograd nodes cut at the engine's progress points, so that the
 # reference's own DDP(model) (train.py:141-148) sees gradients -- and launches its bucket all-reduces -- while backward still runs
@@ -545,8 +546,9 @@ class _TimedBytes:
 def _gn_bwd_name():
     k = lib().vd_gn_bwd_last_kernel()
     if k > 0:
+        split, k = k // 100000000, k % 100000000         # (sibling workgroups per image slab: the SPLIT form of round 5)
         nt, k = k >= 1000000, k % 1000000
-        return f"gn_bwd_fused_kernel<{k // 10000}, {k % 10000}, {'true' if nt else 'false'}>"
+        return f"gn_bwd_fused_kernel<{k // 10000}, {k % 10000}, {'true' if nt else 'false'}, {'true' if split else 'false'}>"
     return "gn_bwd_apply_kernel (two-pass form)" if k < 0 else "gn_bwd_apply_kernel (resample)"
 
 

@@ -173,7 +173,10 @@ class UNetEngine:
         With producer partials the statistics never exist as a tensor: one tiny kernel goes from partials to the table."""
         coef = self._new(x, B, 4, C)
         stats = None
-        if x_parts is not None and H.GN_FOLD:
+        # the folded form lets EVERY workgroup of the apply pass re-reduce the partials of the groups it touches: a few chunks (one per image
+        # from the F(4x4,3x3) forward kernel, four on 64-wide images) cost nothing, HW / 64 of them (tile-engine / F(2x2,3x3) producers on
+        # 32x32 and larger images) would be read back by every 64-pixel workgroup -- those keep the separate finalize launch
+        if x_parts is not None and H.GN_FOLD and max(k for _, _, k in x_parts) <= H.GN_FOLD_MAX_CHUNKS:
             H.gn_apply_from_partials(x, _ld(x), x_parts, gn.weight, gn.bias, film, act, p_drop, seed, rs, y, _ld(y), B, Hh, Ww, C, coef,
                                      GROUPS, EPS)
             return coef
