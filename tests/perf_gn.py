@@ -60,3 +60,9 @@ if __name__ == "__main__":
     case(128, 8, 256, True, 0.2)
     case(128, 64, 192, True, 0.1)
     case(128, 32, 384, True, 0.1)
+    case(128, 64, 384, False, 0.0)
+    case(128, 32, 576, True, 0.1)
+    case(128, 16, 768, True, 0.1)
+    case(128, 8, 768, True, 0.1)
+    case(128, 8, 1536, False, 0.0)
+    case(128, 16, 1536, False, 0.0)

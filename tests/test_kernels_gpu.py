@@ -299,11 +299,12 @@ def ref_gn_block(x, gamma, beta, film, act, resample, mask=None):
 GN_CASES = [  # nimg, C, H, W, film, act, resample
     (2, 64, 8, 8, False, True, 0), (3, 96, 8, 8, True, True, 0), (2, 256, 16, 16, True, True, 0), (2, 64, 8, 8, False, True, 1),
     (2, 64, 8, 8, False, True, 2), (2, 128, 4, 4, False, False, 0), (1, 1152, 8, 8, True, True, 0), (2, 192, 32, 32, False, True, 1),
-    # 64x64 images (round 5): an image slab is shared by four sibling workgroups that exchange their partial sums (SPLIT form of
-    # gn_bwd_fused_kernel) -- 24-channel slabs (C = 192, 96, 384: plain loads), 32-channel slabs (C = 256: non-temporal loads), unit counts
-    # that are not multiples of 8 (3 x 4, 3 x 8 ...), with and without FiLM; the 64x64 down-sampling norm keeps the two-pass form
+    # 64x64 images and wide slabs (round 5): an image slab is shared by sibling workgroups that exchange their partial sums (SPLIT form of
+    # gn_bwd_fused_kernel) wherever its pixel rows are whole 128-byte lines -- C = 256 (32-channel slabs, 4 siblings), C = 384 / 768 (the
+    # 24-channel slab widened to 96 channels: 16 siblings at 64x64, 4 at 32x32, none at 16x16), unit counts that are not multiples of 8;
+    # 96-byte rows (C = 192, 96) and the 64x64 down-sampling norm keep the two-pass form
     (3, 192, 64, 64, True, True, 0), (3, 96, 64, 64, False, True, 0), (2, 384, 64, 64, False, False, 0), (5, 256, 64, 64, True, True, 0),
-    (2, 192, 64, 64, False, True, 1)]
+    (2, 192, 64, 64, False, True, 1), (3, 384, 32, 32, True, True, 0), (2, 768, 16, 16, True, True, 0), (2, 1536, 8, 8, False, True, 0)]
 
 
 @pytest.mark.parametrize("case", GN_CASES)
@@ -345,9 +346,13 @@ def test_gn_forward_backward(H, case):
     H.gn_apply_bwd(nhwc(dy), Cc, xd, ldx, coef, gd, bd, fd, act, 0.0, 0, rs, nhwc(add), Cc, dx, Cc, True, dfilm, dgam, dbet,
                    True, nimg, Hh, Ww, Cc)
     torch.cuda.synchronize()
-    if Hh * Ww == 4096:         # which form ran: 4 siblings per (image, slab) where the geometry is served, the two-pass form (-1) for the resampling norm
-        k = H.lib().vd_gn_bwd_last_kernel()
-        assert (k // 100000000 == 4 and k % 10000 == 1024) if rs == 0 else k == -1, k
+    # which form ran: siblings per (image, slab) of the SPLIT form, the two-pass form (-1), or the plain single-pass form on a 96-channel slab
+    k = H.lib().vd_gn_bwd_last_kernel()
+    want = {(256, 4096, 0): 4, (384, 4096, 0): 16, (384, 1024, 0): 4, (192, 4096, 0): -1, (96, 4096, 0): -1, (192, 4096, 1): -1}.get((Cc, Hh * Ww, rs))
+    if want is not None:
+        assert (k == -1) if want == -1 else (k // 100000000 == want and k % 10000 == 1024), (k, want)
+    if (Cc, Hh * Ww) in ((768, 256), (1536, 64)):
+        assert 0 < k < 100000000 and k >= 1000000, k            # plain form, non-temporal (whole-line) slab
     close(from_nhwc(dx, Cc), dx64 + 1.0, dx32 + 1.0, slack=6, floor=5e-6, name="gn dx")
     close(dgam, dg64 + 1.0, dg32 + 1.0, slack=6, floor=5e-6, name="dgamma")
     close(dbet, db64 + 1.0, db32 + 1.0, slack=6, floor=5e-6, name="dbeta")

@@ -770,9 +770,8 @@ void launch_fused_bwd(int npt, dim3 grid, hipStream_t st, const FusedBwdArgs& f)
 }
 
 // channel slab of the fused backward: whole groups, a multiple of 4 channels, at least 24 channels (96 B per pixel row)
-inline int fused_slab(int C, int G) {
+inline int fused_slab(int C, int G, int min_cs = 24) {      // measured: 16-channel slabs (64 B rows) run 25 % slower, 8-channel ones 2x slower
     const int cg = C / G;
-    constexpr int min_cs = 24;       // measured: 16-channel slabs (64 B rows) run 25 % slower, 8-channel ones 2x slower
     for (int k = 1; k * cg <= 128 && k <= G; ++k) {
         const int cs = k * cg;
         if (cs % 4 == 0 && cs >= min_cs && C % cs == 0) return cs;
@@ -941,7 +940,18 @@ static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int6
         p.part = part;
         // single-pass form whenever one workgroup can hold an image's slab in registers (<= 8 float4 pairs per thread)
         static const bool two_pass = getenv("VD_GN_TWO_PASS") != nullptr;        // A/B switch for profiling
-        const int CS = fused_slab(C, G);
+        int CS = fused_slab(C, G);
+        // slabs whose pixel rows are not whole 128-byte lines (24 channels of C = 192 / 384 / 768, 48 of 1536: 96 / 192-byte rows) stream
+        // poorly; where whole groups also form a 96-channel slab (three full lines per row, non-temporal accesses) that slab is taken
+        // instead, shared by sibling workgroups where it no longer fits one (SPLIT form).  VD_GN_WIDE=0: the narrow slabs (A/B switch).
+        // Same-box, B = 128 (gpurun_out/r05_gn_split*.txt): C = 384 @32x32 220 -> 184 us, @64x64 792 (two-pass) -> 708; C = 192 @64x64
+        // 403 (two-pass) vs 406: kept two-pass; 32-channel slabs (C = 256 / 512: already whole lines) lose 6-12 % when widened: untouched.
+        static const bool wide = !(getenv("VD_GN_WIDE") && atoi(getenv("VD_GN_WIDE")) == 0);
+        if (wide && CS > 0 && CS % 32 != 0 && C >= 384) {
+            const int cg = C / G;
+            for (int k = 1; k * cg <= 128 && k <= G; ++k)
+                if ((k * cg) % 32 == 0 && C % (k * cg) == 0) { CS = k * cg; break; }
+        }
         if (!two_pass && CS > 0 && nimg <= 65535) {
             // 256-thread workgroups (8+ per CU: their load / reduce / store phases overlap) whenever a slab fits 8 float4 pairs per
             // thread, i.e. up to 2048 pairs (16x16 images at 32-channel slabs); 1024 threads only for the larger slabs
@@ -950,12 +960,14 @@ static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int6
             const int TPB = (HW * (CS / 4) > 2048 || (big && HW * (CS / 4) >= 1024)) ? 1024 : 256;
             const int rows = TPB / (CS / 4);
             const int npt = (int)((HW + rows - 1) / rows);
-            // larger slabs (64x64 images): nsplit sibling workgroups per (image, slab), HW / nsplit pixels each (SPLIT form of the kernel;
-            // VD_GN_SPLIT=0: the two-pass form below, A/B switch).  Not for the resampling norms (their pixel gather spans the image).
+            // larger slabs: nsplit sibling workgroups per (image, slab), HW / nsplit pixels each (SPLIT form of the kernel; VD_GN_SPLIT=0:
+            // the two-pass form below, A/B switch).  Not for the resampling norms (their pixel gather spans the image), and only for
+            // whole-line slabs: with 96-byte rows the two-pass form (whole pixel rows in both passes) is the faster one (64x64, C = 192:
+            // 403 us against 490).
             static const bool no_split = getenv("VD_GN_SPLIT") && atoi(getenv("VD_GN_SPLIT")) == 0;
-            if (npt > 8 && !no_split && resample == VD_RS_NONE) {
+            if (npt > 8 && !no_split && resample == VD_RS_NONE && CS % 32 == 0) {
                 int nsplit = 0;
-                for (int k = 2; k <= 8; k *= 2)
+                for (int k = 2; k <= 32; k *= 2)
                     if (HW % k == 0 && (HW / k + (1024 / (CS / 4)) - 1) / (1024 / (CS / 4)) <= 8) { nsplit = k; break; }
                 const long long units = (long long)nimg * (C / CS), upad = (units + 7) / 8 * 8;
                 const size_t cnt_bytes = ((size_t)upad * sizeof(unsigned) + 255) / 256 * 256;
@@ -965,11 +977,9 @@ static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int6
                     FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS, nsplit, reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cnt_bytes),
                                       reinterpret_cast<unsigned*>(ws)};
                     VD_REQUIRE(hipMemsetAsync(ws, 0, cnt_bytes, st) == hipSuccess, "vd_gn_apply_bwd: hipMemsetAsync of the sibling counters failed");
-                    const bool nt = CS % 32 == 0;
                     const dim3 grid((unsigned)(upad * nsplit));
-                    g_last_gn_bwd = 8 * 10000 + 1024 + (nt ? 1000000 : 0) + 100000000 * nsplit;
-                    if (nt) hipLaunchKernelGGL((gn_bwd_fused_kernel<8, 1024, true, true>), grid, dim3(1024), 0, st, f);
-                    else hipLaunchKernelGGL((gn_bwd_fused_kernel<8, 1024, false, true>), grid, dim3(1024), 0, st, f);
+                    g_last_gn_bwd = 8 * 10000 + 1024 + 1000000 + 100000000 * nsplit;
+                    hipLaunchKernelGGL((gn_bwd_fused_kernel<8, 1024, true, true>), grid, dim3(1024), 0, st, f);
                     VD_LAUNCH_CHECK("gn_bwd_fused_kernel<split>");
                     if (!pgb_keep) {
                         hipLaunchKernelGGL(sum_over_images_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pgb, nimg, C, dgamma, dbeta,
