@@ -189,8 +189,8 @@ def traffic_table(wl="cifar10"):
     """HBM bytes per launch from the committed PMC passes of THIS workload (profiles/parse_rocprof.py; separate --pmc passes cannot run
     inside the timed bench, so the figure is a tracked measurement of the same command and says which file it came from): newest round
     first; a workload without a PMC pass of its own gets no table (its `traffic` is null, never another workload's number)"""
-    names = {"cifar10": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"),
-             "celeba": ("r04_celeba_traffic.json",)}[wl]
+    names = {"cifar10": ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"),
+             "celeba": ("r05_celeba_traffic.json", "r04_celeba_traffic.json")}[wl]
     for name in names:
         try:
             return name, json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
@@ -203,8 +203,9 @@ def executed_share(kernel_name):
     """MFMA FLOPs a kernel executes per ALGORITHMIC FLOP recorded for it (v_diffusion/_hip.py records 2*M*N*K of the op each
     launch implements): Winograd F(2x2,3x3) kernels 4/9, the F(4x4,3x3) input gradient 1/4; the fused attention backward recomputes the logits in both of its
     kernels and dP in the second (7 products for the 4 the op defines: 7/4); everything else 1"""
-    if kernel_name.startswith("wino43_"):
-        return 1.0 / 4.0                      # F(4x4,3x3): 36 multiplies per 4x4 output tile where the convolution defines 144
+    if kernel_name.startswith("wino43_") or kernel_name.endswith("weight gradient]"):
+        return 1.0 / 4.0                      # F(4x4,3x3): 36 multiplies per 4x4 output tile where the convolution defines 144 (the weight
+                                              # gradient's 36 planes run on the grouped tile engine, tagged by v_diffusion/_hip.py)
     if kernel_name.startswith("wino_"):
         return 4.0 / 9.0
     if kernel_name.startswith("attn_bwd_"):
@@ -357,9 +358,7 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
         dom = max(agg, key=lambda k: agg[k][1])
         fl, tt_, n = agg[dom]
         tname, tj = traffic_table(wl)
-        # (the 36 xi planes of the F(4x4,3x3) weight gradient run as this instantiation of the grouped tile engine: its rocprof name)
-        key = {"wino43_wgrad_gemm (gemm_dma_kernel<..., grouped> x 36 planes)": "gemm_dma_kernel<128, 128, 1, 1, true, 16, true, true>"}.get(
-            dom, dom.split(" (+")[0])
+        key = dom.split(" [")[0].split(" (+")[0]                             # the rocprof kernel name (tags of v_diffusion/_hip.py stripped)
         traffic = tj[key]["hbm_bytes_per_launch"] if key in tj else None
         ab = _hip.PROFILE_BYTES.get(dom)
         alg_bytes = ab[0] / ab[1] if ab else None
@@ -385,8 +384,9 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
                     "traffic_note": (f"HBM+fabric bytes per launch of this kernel in the same bench command, PMC passes (FETCH_SIZE, WRITE_SIZE: "
                                      f"they cannot run inside the timed region) tracked as profiles/{tname}; traffic_ratio = traffic / "
                                      f"algorithmic bytes (x + y + residual + U read / written once)") if tname else None,
-                    "clock_note": ("peak = 2.4 GHz figure; PMC passes (profiles/r04_wino_pmc.json) put the shader clock at 2.15-2.2 GHz under the "
-                                   "Winograd kernels and the grouped weight-gradient GEMMs (DESIGN.md section 3)") if exe < 1 else None,
+                    "clock_note": ("peak = 2.4 GHz figure; in-kernel clock (s_memtime / s_memrealtime beside the running kernel, "
+                                   "profiles/r05_clock_by_kernel.txt): 2.37 GHz under the Winograd convolution kernels, 2.27-2.28 GHz under the "
+                                   "tile-engine GEMMs, 2.33 GHz over the whole train step"),
                     "launches_per_step": n // 2, "avg_launch_ms": round(tt_ / n * 1e3, 4),
                     "flops_per_launch": round(exe * fl / n / 1e9, 3), "flops_unit": "GFLOP executed on the matrix cores per launch",
                     "algorithmic_flops_per_launch": round(fl / n / 1e9, 3),

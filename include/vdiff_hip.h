@@ -82,7 +82,9 @@ int vd_gemm(const vd_gemm_desc* d, void* stream);
  * launch to the split-operand forms (gemm_split_kernel<...>): each fp32 operand value is split exactly into three bf16 pieces in registers and the six piece
  * products that reach 2^-24 of a.b run on the 16-bit matrix cores with fp32 accumulation.  Same results to fp32 rounding (error against
  * fp64 0.6-0.9 of the fp32 MFMA chain's: tests/test_kernels_gpu.py::test_split_operand_gemm_forms_in_subprocess), 15-26 % shorter
- * launches, -1 to -3 % on a train step (the part is power-bound: DESIGN.md section 3). */
+ * launches, -1 to -3 % on a train step (the part is power-bound: DESIGN.md section 3).  DOMAIN of the split forms: finite operands of
+ * magnitude <= the largest bf16 (3.39e38); a larger or infinite operand yields NaN where the fp32 MFMA yields a finite value or Inf
+ * (bf16(x) rounds to Inf, the residual x - Inf poisons the products); pieces below the smallest normal bf16 are flushed. */
 int vd_gemm_last_tile(void);
 /* `count` (<= 36) same-shape weight-gradient GEMMs in ONE launch -- the 1x1-convolution / linear weight gradients of the blocks of one
  * UNet level (autograd of modules.py:79-80,141-144 w.r.t. the weight), whose operands live in unrelated buffers:

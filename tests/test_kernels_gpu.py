@@ -881,6 +881,54 @@ def test_split_operand_gemm_forms_in_subprocess(H):
     print("split-operand / fp32 MFMA rel-L2 against fp64: " + ", ".join(f"{k} {res['1'][k][1]:.2e}/{res['0'][k][1]:.2e}" for k in res["1"]))
 
 
+SPLIT_DOMAIN_CHILD = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+from v_diffusion import _hip as H
+M, N, K = 256, 128, 64
+g = torch.Generator("cuda").manual_seed(3)
+A = torch.randn((M, K), device="cuda", generator=g)
+B = torch.randn((N, K), device="cuda", generator=g) * 1e-3
+A[5, 7] = 3.0e38          # finite in fp32 and in bf16 (largest bf16: 3.39e38): inside the documented domain
+A[9, 1] = 3.4e38          # finite in fp32, rounds to Inf in bf16: outside
+A[13, 2] = float("inf")
+C = torch.empty((M, N), device="cuda")
+H.gemm(A, B, C, M, N, K, a_kind=0, b_kind=0, lda=K, ldb=K, ldc=N)
+torch.cuda.synchronize()
+ref = A.double() @ B.double().T
+rows = [r for r in range(M) if r not in (9, 13)]
+rel = float(((C[rows].double() - ref[rows]).norm() / ref[rows].norm()))
+print("RESULT " + json.dumps(dict(code=H.lib().vd_gemm_last_tile(), rel=rel, finite5=bool(torch.isfinite(C[5]).all()),
+                                  nan9=int(torch.isnan(C[9]).sum()), inf9=int(torch.isinf(C[9]).sum()),
+                                  nan13=int(torch.isnan(C[13]).sum()), inf13=int(torch.isinf(C[13]).sum()))))
+"""
+
+
+def test_split_operand_gemm_domain(H):
+    """the stated domain of the opt-in split-operand GEMM forms (round-4 advice; include/vdiff_hip.h, csrc/gemm.hip): operands up to the
+    largest bf16 (3.39e38) behave as in the fp32 form; a finite fp32 value beyond it, or an Inf, turns its output row into NaN under
+    VD_GEMM_SPLIT=1 where the fp32 MFMA form gives finite values / Inf -- documented, not hidden; all other rows are unaffected."""
+    import json
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "v-diffusion-torch_amd")
+    res = {}
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", SPLIT_DOMAIN_CHILD % pkg], env=dict(os.environ, VD_GEMM_SPLIT=flag), capture_output=True,
+                           text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+        res[flag] = json.loads(line[0][7:])
+    f32, spl = res["0"], res["1"]
+    assert (spl["code"] // 10 ** 6) // 100 >= 2 and (f32["code"] // 10 ** 6) // 100 < 2, (f32["code"], spl["code"])
+    for r in (f32, spl):
+        assert r["finite5"] and r["rel"] <= 2e-6, r                    # inside the domain: both forms, every ordinary row
+    assert f32["nan9"] == 0 and f32["inf13"] > 0                       # fp32 MFMA: a huge finite operand stays finite / Inf propagates as Inf
+    assert spl["nan9"] > 0 and spl["nan13"] > 0, spl                   # split forms: NaN (the documented difference)
+    print("split-operand domain:", json.dumps(res))
+
+
 # ------------------------------------------------------------------------------------------------ Winograd F(2x2,3x3) convolution
 WINO_CASES = [  # nimg, H, W, Cin, Cout, ldx_extra, ldy_extra      (geometries: every patch-image variant of csrc/wino.hip)
     (2, 32, 32, 64, 64, 0, 0),       # 16 tiles per row: one workgroup = 4 tile rows of one image

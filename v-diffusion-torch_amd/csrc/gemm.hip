@@ -405,6 +405,11 @@ struct GroupOut { float* C[VD_GROUP_MAX]; float* cs[VD_GROUP_MAX]; };
 // and 8 192, normal / positive / wide-range operands): relative L2 error 0.6-0.9 of the fp32 MFMA chain's, worst element 0.6-1.0 of it;
 // three products (hh, hm, mh) are 3-10x worse and are not used.  Same-box rates of the bare loop: 216 TFLOP/s fp32-equivalent against
 // 150 for the fp32 instruction (the chip's power limit, not the issue rate, bounds the 16-bit pipes on random data).
+// DOMAIN (round-4 advice): finite operands of magnitude <= the largest bf16 (3.39e38).  Beyond it bf16(x) rounds to Inf, the residual
+// x - Inf = -Inf and the products give NaN where the fp32 MFMA would give a finite value or Inf; an Inf operand gives NaN (Inf - Inf) instead
+// of Inf; NaN stays NaN; residual pieces below the smallest normal bf16 are flushed (error <= 2^-126, far below fp32 rounding of any normal
+// result).  The switch is opt-in and process-wide: a run whose activations overflow fp32's top binade has diverged either way, but its
+// Inf shows up as NaN one GEMM earlier under VD_GEMM_SPLIT=1 (tests/test_kernels_gpu.py::test_split_operand_gemm_domain).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // {bf16(a), bf16(b)}, a in the low half (v_cvt_pk_bf16_f32)

@@ -443,6 +443,9 @@ WINO43_WGRAD = os.environ.get("VD_WINO43_WGRAD", "1") != "0"   # A/B switch: 0 k
 WINO43_WGRAD_MIN_TILES = int(os.environ.get("VD_WINO43_WGRAD_MIN_TILES", "512"))
 
 
+W43_WGRAD_TAG = "[36 planes of the F(4x4,3x3) weight gradient]"
+
+
 def wgrad43_supported(nimg, H, W, Cin, Cout, ldx, lddy):
     return (WINO and WINO43_WGRAD and nimg * (H // 4) * (W // 4) >= WINO43_WGRAD_MIN_TILES
             and bool(lib().vd_conv3x3_wgrad_wino43_supported(nimg, H, W, Cin, Cout, ldx, lddy)))
@@ -459,11 +462,12 @@ def conv3x3_wgrad_wino43(x, ldx, dy, lddy, nimg, H, W, Cin, Cout, dw, Cin_w, Cou
         return
     with _TimedBytes("wino43_wgrad_transform_kernel", 4.0 * nimg * H * W * (Cin + Cout) * (1 + 2.25)):
         _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 1, stream()), "vd_conv3x3_wgrad_wino43_phase")
-    with _TimedName("wino43_wgrad_gemm (gemm_dma_kernel<..., grouped> x 36 planes)", 2.0 * nimg * H * W * Cout * 9 * Cin):
+    # the 36 planes run as ONE grouped launch of the tile engine: recorded under that instantiation's rocprof name (from vd_gemm_last_tile),
+    # tagged so that the bench knows its recorded work is the direct convolution's 2*M*N*K, of which the planes execute 1/4
+    with _Timed("gemm_dma_kernel<{tile}, 1, 1, true, {kt}, true> " + W43_WGRAD_TAG, 2.0 * nimg * H * W * Cout * 9 * Cin) as t:
         _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 2, stream()), "vd_conv3x3_wgrad_wino43_phase")
     # (its operands are the transformed images: 36 planes of [tiles][Cin] and [tiles][Cout], read once, + the 36 x Cout x Cin result)
-    _note_bytes("wino43_wgrad_gemm (gemm_dma_kernel<..., grouped> x 36 planes)",
-                4.0 * (36.0 * nimg * (H // 4) * (W // 4) * (Cin + Cout) + 36.0 * Cout * Cin))
+    _note_bytes(PROFILE[-1][0], 4.0 * (36.0 * nimg * (H // 4) * (W // 4) * (Cin + Cout) + 36.0 * Cout * Cin))
     with _TimedName("wino43_wgrad_finish_kernel", 0.0):
         _check(lib().vd_conv3x3_wgrad_wino43_phase(*args, 4, stream()), "vd_conv3x3_wgrad_wino43_phase")
 
