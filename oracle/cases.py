@@ -39,8 +39,16 @@ def make_inputs(cfg, B, R, label, seed=0):
     return x, t, y
 
 
+_WEIGHT_CACHE = {}
+
+
 def make_weights(cfg, seed=0):
-    return detrand.fill_state_dict(param_shapes(cfg), seed)
+    """deterministic weights of a config (oracle/detrand.py); generated once per process and config -- the integer hash costs ~20 s for
+    the 267 M parameters of the CelebA model -- and handed out as clones (callers flip requires_grad in place)"""
+    key = (repr(sorted(normalize_cfg(cfg).items())), seed)
+    if key not in _WEIGHT_CACHE:
+        _WEIGHT_CACHE[key] = detrand.fill_state_dict(param_shapes(cfg), seed)
+    return {k: v.clone() for k, v in _WEIGHT_CACHE[key].items()}
 
 
 def kl_case():

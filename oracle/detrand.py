@@ -53,20 +53,43 @@ def randint(name: str, shape, lo: int, hi: int, seed: int = 0) -> torch.Tensor:
     return (u * (hi - lo)).floor().long() + lo
 
 
-def signs(name: str, n: int, seed: int = 0) -> torch.Tensor:
-    """n values of +-1 (float64): the sign pattern of one random projection (gradient digests of the full-size goldens)"""
+def sign_patterns(name: str, n: int, k: int = 4, start: int = 0) -> np.ndarray:
+    """[k][n] values of +-1 (float64): k sign patterns for elements start .. start + n - 1 of a tensor, bits 40 .. 40 + k - 1 of ONE hash per
+    element (the gradient digests of the full-size goldens project every tensor on them)"""
     with np.errstate(over="ignore"):
-        idx = np.arange(n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + _key(name, seed)
+        idx = np.arange(start, start + n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + _key("proj:" + name, 0)
     h = _splitmix64(idx)
-    return torch.from_numpy(1.0 - 2.0 * ((h >> np.uint64(40)) & np.uint64(1)).astype(np.float64))
+    return np.stack([1.0 - 2.0 * ((h >> np.uint64(40 + j)) & np.uint64(1)).astype(np.float64) for j in range(k)])
 
 
-def projections(name: str, g: torch.Tensor, k: int = 4) -> np.ndarray:
-    """k deterministic +-1 projections of a tensor, float64: sum_i s_j(i) g_i for the sign patterns ("proj<j>:" + name).  Unlike a norm
-    they see the position and the sign of every element: a permuted, transposed or sign-flipped block moves them by the size of that
-    block."""
-    v = g.detach().double().flatten().cpu()
-    return np.array([float((signs(f"proj{j}:{name}", v.numel()) * v).sum()) for j in range(k)])
+def _i64(c: int) -> int:
+    """a uint64 constant as the int64 with the same bits (torch has no uint64 arithmetic; int64 products wrap to the same low 64 bits)"""
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    return (x >> s) & ((1 << (64 - s)) - 1)                # logical shift right of int64 bit patterns
+
+
+def projections(name: str, g: torch.Tensor, k: int = 4, chunk: int = 1 << 24) -> np.ndarray:
+    """k deterministic +-1 projections of a tensor, float64: sum_i s_j(i) g_i for the sign patterns of ``sign_patterns(name, ...)`` -- the same
+    splitmix64 hash in torch int64 arithmetic, on the tensor's own device (a GPU test projects 267 M gradient elements in a second; numpy
+    needs half a minute).  Unlike a norm the projections see the position and the sign of every element: a permuted, transposed or
+    sign-flipped block moves them by the size of that block."""
+    v = g.detach().double().flatten()
+    key = int(_key("proj:" + name, 0))
+    out = torch.zeros(k, dtype=torch.float64, device=v.device)
+    for s0 in range(0, v.numel(), chunk):
+        part = v[s0:s0 + chunk]
+        x = torch.arange(s0, s0 + part.numel(), dtype=torch.int64, device=v.device) * _i64(0x2545F4914F6CDD1D) + _i64(key)
+        x = x + _i64(0x9E3779B97F4A7C15)
+        z = (x ^ _lsr(x, 30)) * _i64(0xBF58476D1CE4E5B9)
+        z = (z ^ _lsr(z, 27)) * _i64(0x94D049BB133111EB)
+        h = z ^ _lsr(z, 31)
+        for j in range(k):
+            sgn = 1.0 - 2.0 * ((h >> (40 + j)) & 1).to(torch.float64)
+            out[j] += (sgn * part).sum()
+    return out.cpu().numpy()
 
 
 def fill_state_dict(shapes: dict, seed: int = 0) -> dict:

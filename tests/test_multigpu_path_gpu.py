@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(extra_env):
     env = dict(os.environ, **extra_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--no-sample",
-                        "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-secondary", "--no-torch-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line)

@@ -57,7 +57,7 @@ def _check_grads(g, model, rel=1e-4):
         # norm + leading elements cannot see.  A random projection of an error vector e is ~ |e|_2: 4x the rel-L2 bound.
         if "grad_projs" not in g.files:                     # (fixtures older than round 5: train_loss.npz keeps norm + leading elements)
             continue
-        perr = np.abs(detrand.projections(k, gr) - g["grad_projs"][i]).max()
+        perr = np.abs(detrand.projections(k, p.grad) - g["grad_projs"][i]).max()      # (evaluated on the device)
         worst_proj = max(worst_proj, perr / max(ref_norm, floor / rel))
         assert perr <= 4 * (rel * ref_norm + floor), f"{k}: +-1 projections differ by {perr:.3e} (norm {ref_norm:.3e})"
     print(f"worst gradient-norm error {worst:.2e}, worst projection error {worst_proj:.2e} (of the tensor's norm)")
