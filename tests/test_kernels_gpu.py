@@ -885,7 +885,7 @@ SPLIT_DOMAIN_CHILD = r"""
 import sys, json, torch
 sys.path.insert(0, %r)
 from v_diffusion import _hip as H
-M, N, K = 8192, 256, 256          # (a shape the launcher gives 128-row tiles: the split forms exist for those)
+M, N, K = 32768, 256, 512         # (a shape the launcher gives 128-row tiles: the split forms exist for those)
 g = torch.Generator("cuda").manual_seed(3)
 A = torch.randn((M, K), device="cuda", generator=g)
 B = torch.randn((N, K), device="cuda", generator=g) * 1e-3
