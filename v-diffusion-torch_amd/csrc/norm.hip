@@ -687,6 +687,9 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
             const float* all = f.xbuf + (long long)unit * f.nsplit * 256 + (tid / CS) * 128 + (tid % CS);
             float t = 0.f;
             for (int k = 0; k < f.nsplit; ++k) t += __hip_atomic_load(all + k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a poisoned counter (a sibling never arrived within the spin bound) must be LOUD: NaN sums make this unit's dx, dfilm and
+            // parameter-gradient terms NaN, which the loss / the clip norm of the next step shows at once
+            if (__hip_atomic_load(f.cnt + unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (1u << 20)) t = __builtin_nanf("");
             chs[tid / CS][tid % CS] = t;
         }
         __syncthreads();
