@@ -36,8 +36,9 @@ def conv_fp64(x, w):
     return out
 
 
-for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256), (128, 64, 64, 192, 192), (128, 32, 32, 384, 384),
-                                  (128, 16, 16, 256, 256), (128, 16, 16, 512, 256), (128, 16, 16, 576, 576)):
+SHAPES = ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256), (128, 64, 64, 192, 192), (128, 32, 32, 384, 384),
+          (128, 16, 16, 256, 256), (128, 16, 16, 512, 256), (128, 16, 16, 576, 576))
+for nimg, Hh, Ww, Cin, Cout in SHAPES[:int(os.environ.get("VD_PERF_SHAPES", len(SHAPES)))]:
     g = torch.Generator(DEV).manual_seed(1)
     dy = torch.randn((nimg, Hh, Ww, Cout), device=DEV, generator=g)
     w = torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * (9 * Cin) ** -0.5

@@ -101,6 +101,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #ifndef VD_W43_DPS
 #define VD_W43_DPS 1          /* DMA pieces of tile kt+2 issued per step behind the barrier */
 #endif
+// (round 5, measured and not kept -- tests/probe/r05_dma_order.sh, profiles/r05_dma_order.txt: issuing a K tile's patch pieces, the ones that can miss
+//  to HBM, a whole tile ahead and its U pieces 8 steps ahead instead of the other way round: +3 %; two pieces per step behind the barrier so that
+//  10 of the 11 pieces have a tile of lead: +8 ... +14 %.  The DMA's lead time is not what the waves wait for; bunching its issue costs.)
 // start-up skew of the persistent workgroups: equal work items keep all 256 CUs in phase, so every item boundary is one chip-wide burst
 // of residual reads and output writes (FINDINGS round 4: the residual costs 15 % of a forward launch).  Workgroup w of an XCD sleeps
 // ((w >> 3) % NPH) * SLEEPS * ~3.7 us before its first item (s_sleep 127 = 8128 cycles): NPH phases that stay apart for the whole launch.
