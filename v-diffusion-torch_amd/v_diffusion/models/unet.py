@@ -60,6 +60,7 @@ class _UNetFn(torch.autograd.Function):
             return model._to_nchw(out)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # hand-written kernels: a second-order backward through them raises instead of returning constants
     def backward(ctx, dout):
         model, tape = ctx.model, ctx.tape
         if tape is None:
@@ -163,6 +164,7 @@ class _SegFn(torch.autograd.Function):
         return carrier.new_empty((1,), dtype=torch.float32)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         run, j = ctx.run, ctx.j
         with torch.cuda.device(run.device) if run.device.type == "cuda" else _nullctx():
