@@ -976,7 +976,9 @@ extern "C" int vd_conv3x3_wino43_fwd(const float* xin, int64_t ldx, const float*
     a.items_per_img = W == 64 ? H / 16 : 1;
     a.ngrp = W == 16 ? nimg / 4 : nimg * a.items_per_img;
     a.ncb = Cout / TN;
-    a.bias = bias; a.res = res; a.ldr = ldres; a.stats = stats_part; a.chunks_per_img = a.items_per_img;
+    a.bias = bias; a.res = res; a.ldr = ldres; a.stats = stats_part;
+    a.chunks_per_img = (H * W) / vd_conv3x3_wino43_fwd_chunk_rows(H, W);      // ONE statement of the chunk size: what the consuming norm is told
+    VD_REQUIRE(a.chunks_per_img == a.items_per_img, "vd_conv3x3_wino43_fwd: statistics chunks (%d per image) do not match the work items (%d)", a.chunks_per_img, a.items_per_img);
     const long long items = (long long)a.ngrp * a.ncb;
     VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_wino43_fwd: too many work items");
     a.nitems = (int)items;
