@@ -392,6 +392,9 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
                     "clock_note": ("peak = 2.4 GHz figure; in-kernel clock (s_memtime / s_memrealtime beside the running kernel, "
                                    "profiles/r05_clock_by_kernel.txt): 2.37 GHz under the Winograd convolution kernels, 2.27-2.28 GHz under the "
                                    "tile-engine GEMMs, 2.33 GHz over the whole train step"),
+                    "peak_note": ("split-operand GEMM (three bf16 pieces per fp32 operand, six products on the 16-bit matrix cores): achieved counts fp32-"
+                                  "equivalent FLOPs against the fp32-MFMA peak; the form's own ceiling is the dense bf16 MFMA rate / 6 = 417 TFLOP/s, and "
+                                  "it runs power-limited at 1.88 GHz (profiles/r05_clock_split.txt)") if "gemm_split" in dom else None,
                     "launches_per_step": n // 2, "avg_launch_ms": round(tt_ / n * 1e3, 4),
                     "flops_per_launch": round(exe * fl / n / 1e9, 3), "flops_unit": "GFLOP executed on the matrix cores per launch",
                     "algorithmic_flops_per_launch": round(fl / n / 1e9, 3),
@@ -580,10 +583,15 @@ def main():
         except Exception as e:                      # a baseline that cannot run must not take the measured line down with it
             torch_base = {"value": None, "kind": "port on ATen/MIOpen", "baseline_only": True, "error": f"{type(e).__name__}: {e}"[:300]}
 
+    # the arithmetic the path computes in: fp32 operands and results everywhere; Winograd convolutions and the fused attention on the fp32 MFMA
+    # instructions; the tile-engine GEMMs (1x1 convolutions, linears, attention products, weight-gradient planes) by default through split
+    # operands -- every fp32 value the exact sum of three bf16 pieces, six piece products on the 16-bit matrix cores, fp32 accumulation,
+    # error against fp64 0.6-0.9 of the fp32 MFMA chain's (round-4 review item 6 ii; VD_GEMM_SPLIT=0 = fp32 MFMA everywhere)
+    dtype_label = "fp32 (bf16x3 split products in the tile-engine GEMMs)" if _hip.lib().vd_gemm_split_forms() else "fp32"
     if rank == 0:
         line = {"metric": "train_images_per_sec", "value": round(r["value"], 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+                "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
                 "config": {"workload": r["name"] + " full train step: q_sample+fwd+snr_trunc v-loss+bwd+grad all-reduce+clip+AdamW+EMA; "
                                        "second figure: DDIM-50 CFG w=1 sampling",
                            "global_batch": world * B, "per_gpu_batch": B, "resolution": RES, "parallelism": f"dp{world}",

@@ -78,14 +78,16 @@ int vd_gemm(const vd_gemm_desc* d, void* stream);
  * kernel instantiation gemm_dma_kernel<BM,BN,a_kind,b_kind,splitk,KT,TR> the launch went to; F bit 0 = TR, transposed-accumulator
  * epilogue (launches without output statistics); F >= 2: split-operand form, below; KT = 0 means the register-staged fallback
  * gemm_kernel<BM,BN,a_kind,b_kind,splitk>).
- * Environment, read once per process: VD_GEMM_SPLIT=1 (default 0) sends the 128-row tiles of vd_gemm and every vd_gemm_grouped_wgrad
- * launch to the split-operand forms (gemm_split_kernel<...>): each fp32 operand value is split exactly into three bf16 pieces in registers and the six piece
+ * Environment, read once per process: VD_GEMM_SPLIT (default 1 since round 5; 0 = fp32 MFMA everywhere, the A/B form) sends the 128-row tiles of vd_gemm and
+ * every vd_gemm_grouped_wgrad launch to the split-operand forms (gemm_split_kernel<...>): each fp32 operand value is split exactly into three bf16 pieces in registers and the six piece
  * products that reach 2^-24 of a.b run on the 16-bit matrix cores with fp32 accumulation.  Same results to fp32 rounding (error against
  * fp64 0.6-0.9 of the fp32 MFMA chain's: tests/test_kernels_gpu.py::test_split_operand_gemm_forms_in_subprocess), 15-26 % shorter
- * launches, -1 to -3 % on a train step (the part is power-bound: DESIGN.md section 3).  DOMAIN of the split forms: finite operands of
+ * launches (in-kernel clock 1.88 GHz instead of 2.28: the 16-bit pipes ARE power-limited on random data), -2.3 % on a train step of either
+ * workload (profiles/r05_split_step_ab.txt); vd_gemm_split_forms() tells which form is in effect.  DOMAIN of the split forms: finite operands of
  * magnitude <= the largest bf16 (3.39e38); a larger or infinite operand yields NaN where the fp32 MFMA yields a finite value or Inf
  * (bf16(x) rounds to Inf, the residual x - Inf poisons the products); pieces below the smallest normal bf16 are flushed. */
 int vd_gemm_last_tile(void);
+int vd_gemm_split_forms(void);   /* 1: the split-operand forms are in effect for this process (VD_GEMM_SPLIT, default 1), 0: fp32 MFMA everywhere */
 /* `count` (<= 36) same-shape weight-gradient GEMMs in ONE launch -- the 1x1-convolution / linear weight gradients of the blocks of one
  * UNet level (autograd of modules.py:79-80,141-144 w.r.t. the weight), whose operands live in unrelated buffers:
  *   C[e][M][N] (pitch ldc) = A[e]^T B[e],  A[e] = dY [K][M] (pitch lda), B[e] = X [K][N] (pitch ldb)   (= vd_gemm with COL / COL kinds)

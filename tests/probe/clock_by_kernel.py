@@ -26,7 +26,12 @@ side = torch.cuda.Stream()
 NWG, NSAMP, PERIOD = 8, 400, 100_000          # one witness per XCD, 400 stamps, 1 ms apart (100 MHz ticks)
 
 
+ONLY = [w for w in os.environ.get("VD_CLOCK_ONLY", "").split(",") if w]      # substrings of the entries to run (default: all)
+
+
 def measure(name, fn, flops=0.0, nbytes=0.0, lead_s=1.5):
+    if ONLY and not any(w in name for w in ONLY):
+        return
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

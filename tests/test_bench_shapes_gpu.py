@@ -571,6 +571,20 @@ def test_cifar_train_step_b64_fused_attention_hd256():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_cifar_train_step_b64_fp32_mfma_gemms():
+    """the same step with VD_GEMM_SPLIT=0 (read once per process): the tile-engine GEMMs on the fp32 MFMA instructions (the shipped default
+    since round 5 are the split-operand forms), against the same oracle"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "--no-header", "-p", "no:cacheprovider",
+                        "-k", "test_cifar_train_step_b64_vs_oracle"], env=dict(os.environ, VD_GEMM_SPLIT="0"), capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_cifar_train_step_b64_direct_convolutions():
     """the same step with the Winograd path switched off (VD_WINO=0, read once per process): the KT = 16 direct
     implicit-GEMM instantiations inside the full step, against the same oracle"""

@@ -764,12 +764,14 @@ def test_sumsq_adamw_ema(H):
 
 
 @pytest.mark.parametrize("knobs", [{"VD_GEMM_KT": "16", "VD_GEMM_TILE": "128"}, {"VD_GEMM_LEGACY": "1"}, {"VD_GEMM_TR": "0"},
-                                   {"VD_GEMM_KT": "16", "VD_GEMM_TILE": "128", "VD_GEMM_TR": "0"}])
+                                   {"VD_GEMM_KT": "16", "VD_GEMM_TILE": "128", "VD_GEMM_TR": "0"}, {"VD_GEMM_SPLIT": "0"},
+                                   {"VD_GEMM_SPLIT": "0", "VD_GEMM_KT": "16", "VD_GEMM_TILE": "128"}])
 def test_kernel_variants_in_subprocess(H, knobs):
     """Instantiations the plain run does not select: the KT = 16 form of the 128x128 LDS-DMA kernel (picked for launches
     of >= 1024 workgroups), the register-staged fallback kernel (picked when a leading dimension exceeds the 32-bit
     buffer-offset range), and the column-per-lane epilogue for launches that the plain run sends to the transposed-
-    accumulator form (VD_GEMM_TR=0).  Force each through its knob and re-run the GEMM / conv parity cases in a child
+    accumulator form (VD_GEMM_TR=0), and -- since the split-operand forms became the default in round 5 -- the fp32-MFMA forms of the
+    128-row tiles (VD_GEMM_SPLIT=0).  Force each through its knob and re-run the GEMM / conv parity cases in a child
     process (the knobs are read once per process)."""
     import os
     import subprocess

@@ -151,6 +151,20 @@ def test_full_size_unet_with_f23_forward_in_subprocess():
     print("\n".join(l for l in r.stdout.splitlines() if "out err" in l))
 
 
+def test_full_size_unet_with_fp32_mfma_gemms_in_subprocess():
+    """the same full-size comparison with VD_GEMM_SPLIT=0 (read once per process): every tile-engine GEMM on the fp32 MFMA instructions
+    instead of the shipped split-operand forms (round 5: default on) -- the A/B form must stay inside the same bound"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-s", "--no-header", "-p", "no:cacheprovider",
+                        "-k", "test_full_size_unet_vs_golden"], env=dict(os.environ, VD_GEMM_SPLIT="0"), capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    print("\n".join(l for l in r.stdout.splitlines() if "out err" in l))
+
+
 def test_small_batches_follow_the_occupancy_rule_in_subprocess():
     """vd_conv3x3_wino43_preferred (round-4 advice): with fewer F(4x4,3x3) work items than 3/4 of the CUs' rounds the engine keeps the
     F(2x2,3x3) kernels (four times as many items at 3/8 of the time each).  The same full-size golden comparison with the rule ON

@@ -24,7 +24,7 @@ namespace {
 
 constexpr int KT = 32;   // K tile
 #ifndef VD_GEMM_SPLIT_DEFAULT
-#define VD_GEMM_SPLIT_DEFAULT 0
+#define VD_GEMM_SPLIT_DEFAULT 1      /* round 5: the split-operand forms are the shipped default (VD_GEMM_SPLIT=0: fp32 MFMA everywhere, the A/B form) */
 #endif
 
 struct GemmArgs {
@@ -1242,11 +1242,14 @@ bool use_tr(const GemmArgs& a, bool wgrad) {
     return a.sCb % 4 == 0 && a.sCh % 4 == 0 && a.slab_stride % 4 == 0;
 }
 
-// VD_GEMM_SPLIT (read once): 1 = the split-operand forms (SPL above) wherever they are built, 0 = fp32 MFMA everywhere
+// VD_GEMM_SPLIT (read once): 1 (default since round 5) = the split-operand forms (SPL above) wherever they are built, 0 = fp32 MFMA everywhere
 static bool split_forms() {
     static const int v = [] { const char* e = getenv("VD_GEMM_SPLIT"); return e ? atoi(e) : VD_GEMM_SPLIT_DEFAULT; }();
     return v != 0;
 }
+}  // namespace
+extern "C" int vd_gemm_split_forms(void) { return split_forms() ? 1 : 0; }
+namespace {
 template <int BM, int BN, int AK, int BK, bool SPLITK>
 void launch(const GemmArgs& a, dim3 grid, hipStream_t st, int ktile) {
     // the only tile with a KT = 16 instantiation; an unsplit conv weight gradient never takes it (ktile_for): those two

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "vd_reserved_cus": (C.c_int, []),
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_last_tile": (C.c_int, []),
+    "vd_gemm_split_forms": (C.c_int, []),
     "vd_gemm_grouped_wgrad_ws_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "vd_gemm_grouped_wgrad_auto_split": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "vd_gemm_grouped_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
