@@ -645,8 +645,7 @@ def attn_supported(L, hd, backward):
 
 
 def attn_use_fused(L, hd, rows, training):
-    """Which attention path a block takes.  Inference: the fused forward wherever it is served, except head dim 256 at L >= 256 under the
-    split-operand GEMMs (below).
+    """Which attention path a block takes.  Inference: the fused forward wherever it is served (faster at every measured shape).
     Training (forward + backward with recomputation: 9 products where the three-launch path runs 6) by same-box measurement at
     batch 128 (tests/perf_attn.py, MI355X): head dim 64 fused except at L = 256 (0.144 vs 0.128 ms); head dim 128 / 256 unfused (the
     backward kernels hold Q/dO or K/V fragments of the whole head dim in registers: one wave per SIMD at head dim 256 -- L = 1024:
@@ -654,15 +653,10 @@ def attn_use_fused(L, hd, rows, training):
     path is the only sensible one.  VD_FUSED_ATTN=2 forces the fused kernels wherever served (parity tests of the whole step)."""
     if not attn_supported(L, hd, training):
         return False
-    if FUSED_ATTN == "2":
+    if not training or FUSED_ATTN == "2":
         return True
     if 4.0 * rows * L * L >= float(1 << 32):
         return True
-    if not training:
-        # round 5: with the tile-engine GEMMs on split operands (the default) the three launches beat the fused forward at head dim 256 from
-        # L = 256 on (256 rows: 0.155 vs 0.167 ms at L = 256, 2.06 vs 2.33 at L = 1024; profiles/r05_attn_policy.txt); with VD_GEMM_SPLIT=0 the
-        # fused kernel wins there too (0.165 vs 0.177, 2.18 vs 2.49)
-        return not (hd == 256 and L >= 256 and bool(lib().vd_gemm_split_forms()))
     return hd == 64 and L != 256
 
 
