@@ -132,7 +132,7 @@ def torch_rocm_baseline(wl="cifar10", batch=128, steps=3, warmup=2, device="cuda
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
     # train.py:237 sets cudnn.benchmark (MIOpen then times every solver per shape: 774 img/s here, but 6.5 minutes of search on a fresh
-    # box -- gpurun_out/r05_torch_baseline_modes.txt); the default bench run must finish within minutes, so the baseline leg runs MIOpen's
+    # box -- profiles/r05_torch_baseline_modes.txt); the default bench run must finish within minutes, so the baseline leg runs MIOpen's
     # immediate mode (758 img/s: 2 % less) unless VD_TORCH_BASELINE_BENCHMARK=1
     bench_mode = os.environ.get("VD_TORCH_BASELINE_BENCHMARK", "0") != "0"
     torch.backends.cudnn.benchmark = bench_mode

@@ -947,7 +947,7 @@ static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int6
         // slabs whose pixel rows are not whole 128-byte lines (24 channels of C = 192 / 384 / 768, 48 of 1536: 96 / 192-byte rows) stream
         // poorly; where whole groups also form a 96-channel slab (three full lines per row, non-temporal accesses) that slab is taken
         // instead, shared by sibling workgroups where it no longer fits one (SPLIT form).  VD_GN_WIDE=0: the narrow slabs (A/B switch).
-        // Same-box, B = 128 (gpurun_out/r05_gn_split*.txt): C = 384 @32x32 220 -> 184 us, @64x64 792 (two-pass) -> 708; C = 192 @64x64
+        // Same-box, B = 128 (profiles/r05_gn_split.txt, r05_gn_split2.txt, r05_gn_wide.txt): C = 384 @32x32 220 -> 184 us, @64x64 792 (two-pass) -> 708; C = 192 @64x64
         // 403 (two-pass) vs 406: kept two-pass; 32-channel slabs (C = 256 / 512: already whole lines) lose 6-12 % when widened: untouched.
         static const bool wide = !(getenv("VD_GN_WIDE") && atoi(getenv("VD_GN_WIDE")) == 0);
         if (wide && CS > 0 && CS % 32 != 0 && C >= 384) {

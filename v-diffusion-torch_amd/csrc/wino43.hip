@@ -107,7 +107,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 // start-up skew of the persistent workgroups: equal work items keep all 256 CUs in phase, so every item boundary is one chip-wide burst
 // of residual reads and output writes (FINDINGS round 4: the residual costs 15 % of a forward launch).  Workgroup w of an XCD sleeps
 // ((w >> 3) % NPH) * SLEEPS * ~3.7 us before its first item (s_sleep 127 = 8128 cycles): NPH phases that stay apart for the whole launch.
-// (round 5, measured and NOT kept -- tests/probe/r05_skew.sh, gpurun_out/r05_skew.txt, FINDINGS round 5: a start-up skew of the persistent
+// (round 5, measured and NOT kept -- tests/probe/r05_skew.sh, profiles/r05_skew.txt, FINDINGS round 5: a start-up skew of the persistent
 //  workgroups, 2 / 4 / 8 phases up to 3.7 ... 26 us apart, so that the item-boundary bursts of residual reads and output writes of the 256 CUs
 //  do not coincide: 0.471-0.483 ms against 0.478 at 256 -> 256 @32x32 with residual, i.e. nothing; one static s_setprio 1 for waves 4-7:
 //  +1.5 %.  The CUs being in phase is not what the residual costs.)
