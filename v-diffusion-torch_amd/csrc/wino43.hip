@@ -101,7 +101,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 #ifndef VD_W43_DPS
 #define VD_W43_DPS 1          /* DMA pieces of tile kt+2 issued per step behind the barrier */
 #endif
-// (round 5, built, correct and not kept -- tests/probe/r05_uglobal.sh, profiles/r05_uglobal.txt: the U fragments straight from global memory (one coalesced
+// (round 5, built, correct and not kept -- profiles/r05_uglobal.txt: the U fragments straight from global memory (one coalesced
 //  buffer_load_b128 per MFMA step from the packed image, ring of 3 / 6 / 9 fragments across K tiles, no U pieces in the LDS-DMA plan: -52 % LDS traffic):
 //  0.673 / 0.555 / 0.552 ms against 0.432 -- the vector-memory path delivers a wave's KiB at half the LDS rate, and eight waves ask for 144 KB per K tile.)
 // (round 5, measured and not kept -- tests/probe/r05_dma_order.sh, profiles/r05_dma_order.txt: issuing a K tile's patch pieces, the ones that can miss
