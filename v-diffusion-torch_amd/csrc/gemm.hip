@@ -435,7 +435,8 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& H, bf16x8& M
 #define VD_KT16_BLOCKS 4
 #endif
 #ifndef VD_SPL_BLOCKS
-#define VD_SPL_BLOCKS 3       /* workgroups per CU of the split-operand KT = 16 forms (168 registers) */
+#define VD_SPL_BLOCKS 2       /* workgroups per CU the split-operand KT = 16 forms are compiled for (round 5, same-box whole-step A/B of 2 / 3 / 4,
+                                 profiles/r05_spl_blocks.txt: CIFAR 58.12 / 57.51 vs 58.58 / 57.70 vs 58.50 / 57.65 ms, CelebA 292.7 / 290.1 vs 293.9 / 290.8 vs 295.5 / 297.4) */
 #endif
 // the kernel body; instantiated by gemm_dma_kernel (SPL = false: fp32 MFMA) and gemm_split_kernel (SPL = true) below
 template <int BM, int BN, int AK, int BK, bool SPLITK, int KT, bool TR, bool GROUPED, bool SPL>
