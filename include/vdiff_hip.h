@@ -146,6 +146,8 @@ int vd_wino_wgrad_last_kernel(void);
  * code): per-wave phase timestamps of the next vd_conv3x3_wino / vd_conv3x3_wgrad_wino launches into buf (64 x uint64 per
  * workgroup), NULL = off */
 int vd_wino_set_probe(unsigned long long* buf);
+/* the same for the F(4x4,3x3) forward and input-gradient launches -- tests/probe/w43_phases.py: 16 x uint64 per (workgroup, wave, item round < 4) */
+int vd_wino43_set_probe(unsigned long long* buf);
 #endif
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
 /* ---- input gradient of the same convolution as Winograd F(4x4, 3x3) (csrc/wino43.hip): 36 multiplies per 4x4 output tile where

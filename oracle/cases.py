@@ -39,6 +39,17 @@ def make_inputs(cfg, B, R, label, seed=0):
     return x, t, y
 
 
+def full_size_inputs(cfg, B, R, label):
+    """inputs of the full-size UNet fixtures (tests/golden/unet_cifar10_cond.npz, unet_celeba.npz): ONE statement for the generator and
+    the tests that read them.  Single-label models: every row labelled except the last, which is UNLABELLED (class 0: the reference
+    adds no class embedding, unet.py:289-295); multi-tag models: make_inputs' all-zero first row."""
+    x, t, y = make_inputs(cfg, B, R, label)
+    if label == "single":
+        y = y.clamp(min=1)
+        y[-1] = 0
+    return x, t, y
+
+
 _WEIGHT_CACHE = {}
 
 

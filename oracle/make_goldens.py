@@ -72,7 +72,7 @@ def main():
     RefUNet, RefGD, ref_get_schedule, refdiff, reffn = import_reference()
     sys.path.insert(0, ROOT)
     from oracle import unet_ref, diffusion_ref as dref, detrand
-    from oracle.cases import TINY, CIFAR_COND, CELEBA, make_inputs, make_weights
+    from oracle.cases import TINY, CIFAR_COND, CELEBA, make_inputs, make_weights, full_size_inputs
 
     def build_ref(cfg):
         m = RefUNet(**cfg)
@@ -119,9 +119,7 @@ def main():
         m, sd = build_ref(cfg)
         nparam = sum(p.numel() for p in m.parameters())
         print("  params:", nparam)
-        x, t, y = make_inputs(cfg, B, R, label)
-        if label == "single":
-            y = y.clamp(min=1)
+        x, t, y = full_size_inputs(cfg, B, R, label)     # (single-label: one labelled row and one UNLABELLED row)
         gout = detrand.normal("gout", (B, cfg["out_channels"], R, R), 1)
         out = m(x, t, None if y is None else y.clone())
         (out * gout).sum().backward()

@@ -9,11 +9,10 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# The parity suite runs the kernels the BENCHMARKED batches run, at batches the CPU oracle can follow: the occupancy rule that hands small
-# batches to the finer F(2x2,3x3) items (vd_conv3x3_wino43_preferred, round 5) is switched off for the session, so a B = 2 ... 64 test still
-# goes through the F(4x4,3x3) kernels of the B = 128 step.  The rule itself -- and the network under it -- is tested where it is named:
-# tests/test_unet_gpu.py::test_small_batches_follow_the_occupancy_rule_in_subprocess.
-os.environ.setdefault("VD_WINO43_OCC", "0")
+# The suite runs the PRODUCT DEFAULT dispatch: small batches follow the occupancy rule (vd_conv3x3_wino43_preferred), i.e. the finer
+# F(2x2,3x3) items where F(4x4,3x3) would leave CUs idle.  The handful of tests that must push a B <= 64 network through the F(4x4,3x3) kernels of
+# the B = 128 step set VD_WINO43_OCC=0 in their own subprocess (test_unet_gpu.py::test_small_batch_networks_through_the_f43_kernels_in_subprocess,
+# test_bench_shapes_gpu.py::test_train_steps_through_the_f43_kernels_in_subprocess).
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -585,6 +585,21 @@ def test_cifar_train_step_b64_fp32_mfma_gemms():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_train_steps_through_the_f43_kernels_in_subprocess():
+    """the B = 64 CIFAR-10 and B = 8 CelebA steps with the occupancy rule OFF (VD_WINO43_OCC=0): under the product default (what this suite
+    runs) their 16x16 / small layers take the finer F(2x2,3x3) items; here every layer F(4x4,3x3) serves runs it, as in the B = 128 step,
+    against the same oracle"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "--no-header", "-p", "no:cacheprovider",
+                        "-k", "test_cifar_train_step_b64_vs_oracle or test_celeba_train_step_b8_vs_oracle"], env=dict(os.environ, VD_WINO43_OCC="0"),
+                       capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_cifar_train_step_b64_direct_convolutions():
     """the same step with the Winograd path switched off (VD_WINO=0, read once per process): the KT = 16 direct
     implicit-GEMM instantiations inside the full step, against the same oracle"""
@@ -814,6 +829,25 @@ def test_cifar_ddim50_cfg1_sampler_256_rows():
     print(f"CIFAR DDIM-50 w=1, 256 rows: row independence ok, oracle max err {d:.2e} (chain end), {d0:.2e} (step 0)")
 
 
+def _oracle_rows_of_the_full_batch(cfg, sd, rows, noise, x0, t, y, o_full, l_full, R):
+    """DIRECT oracle comparison at the benchmarked batch (round-5 review 1d): the CPU oracle evaluates `rows` of the B = 128 batch -- the
+    network on x_t = noise rows (what run_dx feeds) and the per-sample training loss -- and the corresponding rows of the HIP results
+    of the B = 128 launches must match within the bounds of the small-batch oracle tests (output 2e-5 (+1e-5 of scale), loss rtol 2e-4)."""
+    from oracle import unet_ref, diffusion_ref as dref
+    rows = torch.tensor(rows)
+    with torch.no_grad():
+        sdo = {k: v for k, v in sd.items()}
+        den = lambda a, b, c: unet_ref.unet_forward(sdo, cfg, a, b, c)
+        o_ref = den(noise[rows], t[rows], y[rows].clone())
+        l_ref = dref.train_loss(den, dref.make_schedule("cosine"), x0[rows], t[rows], y[rows].clone(), noise[rows], "v", "snr_trunc")
+    scale = o_ref.abs().max().item()
+    oerr = (o_full[rows] - o_ref).abs().max().item()
+    assert oerr <= 2e-5 + 1e-5 * scale, f"rows {rows.tolist()} of the B = {len(o_full)} output differ from the oracle by {oerr:.3e} (scale {scale:.3e})"
+    assert torch.allclose(l_full[rows], l_ref, rtol=2e-4, atol=1e-6), (l_full[rows], l_ref)
+    print(f"rows {rows.tolist()} of the B = {len(o_full)} batch vs the CPU oracle: output err {oerr:.2e} (scale {scale:.2e}), "
+          f"loss rel err {((l_full[rows] - l_ref).abs() / l_ref.abs()).max().item():.2e}")
+
+
 def test_cifar_train_step_b128_rows_and_halves():
     """One CIFAR-cond train step at the benchmarked batch, B = 128 (drop_rate = 0), tied to the oracle-checked B = 64 step through the
     two properties the domain offers (reference train_utils.py:137-154: per-sample losses, loss.mean().backward()):
@@ -864,6 +898,7 @@ def test_cifar_train_step_b128_rows_and_halves():
     o_full, dx_full = run_dx(full)
     o_8, dx_8 = run_dx(full[:8])
     assert (o_full[:8] - o_8).abs().max().item() <= 2e-5 * max(o_8.abs().max().item(), 1.0)
+    _oracle_rows_of_the_full_batch(cfg, sd, [0, 1, 64, 127], noise, x0, t, y, o_full, l_full, 32)
     sc = dx_8.abs().max().item()
     d = (dx_full[:8] - dx_8).abs().max().item()
     assert d <= 2e-5 * sc, f"dx of rows 0-7: B=128 vs B=8 differ by {d:.3e} on scale {sc:.3e}"
@@ -935,6 +970,8 @@ def _celeba_rows_and_halves(B):
     sc = dx_8.abs().max().item()
     d = (dx_full[:8] - dx_8).abs().max().item()
     assert d <= 2e-5 * sc, f"dx of rows 0-7: B={B} vs B=8 differ by {d:.3e} on scale {sc:.3e}"
+    if B == 128:
+        _oracle_rows_of_the_full_batch(cfg, sd, [0, 1, 64, 127], noise, x0, t, y, o_full, l_full, 64)
     del o_full, dx_full
     l_a, g_a = run(full[:B // 2])
     l_b, g_b = run(full[B // 2:])

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import unet_ref, diffusion_ref as dref, detrand
-from oracle.cases import TINY, CIFAR_COND, CELEBA, make_inputs, make_weights, kl_case
+from oracle.cases import TINY, CIFAR_COND, CELEBA, make_inputs, make_weights, kl_case, full_size_inputs
 
 
 def _load(golden_dir, name):
@@ -61,9 +61,9 @@ def test_param_order_matches_reference(golden_dir):
 def test_cifar_unet_forward(golden_dir):
     g = _load(golden_dir, "unet_cifar10_cond.npz")
     sd = make_weights(CIFAR_COND)
-    x, t, y = make_inputs(CIFAR_COND, 2, 32, "single")
+    x, t, y = full_size_inputs(CIFAR_COND, 2, 32, "single")          # (one labelled row, one unlabelled)
     with torch.no_grad():
-        out = unet_ref.unet_forward(sd, CIFAR_COND, x, t, y.clamp(min=1))
+        out = unet_ref.unet_forward(sd, CIFAR_COND, x, t, y)
     np.testing.assert_allclose(out.numpy(), g["out"], atol=1e-5, rtol=0)
 
 

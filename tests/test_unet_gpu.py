@@ -55,8 +55,7 @@ def _check_grads(g, model, rel=1e-4):
         # four +-1 projections over the WHOLE tensor (oracle/detrand.py::projections; fixtures regenerated from the reference in round
         # 5): a permutation, transposition or sign error anywhere in the tensor moves them by the size of the affected block, which
         # norm + leading elements cannot see.  A random projection of an error vector e is ~ |e|_2: 4x the rel-L2 bound.
-        if "grad_projs" not in g.files:                     # (fixtures older than round 5: train_loss.npz keeps norm + leading elements)
-            continue
+        assert "grad_projs" in g.files, "fixture without +-1 projections: regenerate it with oracle/make_goldens.py"
         perr = np.abs(detrand.projections(k, p.grad) - g["grad_projs"][i]).max()      # (evaluated on the device)
         worst_proj = max(worst_proj, perr / max(ref_norm, floor / rel))
         assert perr <= 4 * (rel * ref_norm + floor), f"{k}: +-1 projections differ by {perr:.3e} (norm {ref_norm:.3e})"
@@ -112,9 +111,7 @@ def test_full_size_unet_vs_golden(vd, golden_dir, name, cfgname, B, R, label):
     cfg = getattr(cases, cfgname)
     g = _gold(golden_dir, f"unet_{name}.npz")
     model, _ = _build(vd, cfg, train=False)
-    x, t, y = cases.make_inputs(cfg, B, R, label)
-    if label == "single":
-        y = y.clamp(min=1)
+    x, t, y = cases.full_size_inputs(cfg, B, R, label)      # (CIFAR-10: the last row is UNLABELLED -- class 0, no class embedding)
     gout = detrand.normal("gout", (B, cfg["out_channels"], R, R), 1)
     out = model(x.to(DEV), t.to(DEV), y.to(DEV))
     err = np.abs(out.detach().cpu().numpy() - g["out"]).max()
@@ -165,16 +162,14 @@ def test_full_size_unet_with_fp32_mfma_gemms_in_subprocess():
     print("\n".join(l for l in r.stdout.splitlines() if "out err" in l))
 
 
-def test_small_batches_follow_the_occupancy_rule_in_subprocess():
+def test_occupancy_rule_arithmetic():
     """vd_conv3x3_wino43_preferred (round-4 advice): with fewer F(4x4,3x3) work items than 3/4 of the CUs' rounds the engine keeps the
-    F(2x2,3x3) kernels (four times as many items at 3/8 of the time each).  The same full-size golden comparison with the rule ON
-    (VD_WINO43_OCC=1, the product default; this suite switches it off in conftest.py): B = 2 / B = 1 networks then run every layer
-    the rule hands back to F(2x2,3x3), inside the same bound.  The rule's arithmetic itself is checked on the spot."""
+    F(2x2,3x3) kernels (four times as many items at 3/8 of the time each).  The rule is the product default and what this suite runs under
+    (the B = 2 / B = 1 golden networks, the tiny networks and the sampler chains go through whatever it picks); its arithmetic is checked here."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    import subprocess
-    import sys
     from v_diffusion import _hip
+    assert _hip.WINO43_OCC, "the suite must run the product default (VD_WINO43_OCC unset)"
     ncu = 256 - int(_hip.lib().vd_reserved_cus())
     pref = _hip.lib().vd_conv3x3_wino43_preferred
     for nimg, Hh, Ww, N in ((128, 32, 32, 256), (256, 32, 32, 256), (16, 32, 32, 256), (24, 32, 32, 256), (8, 16, 16, 256), (128, 16, 16, 256),
@@ -184,10 +179,20 @@ def test_small_batches_follow_the_occupancy_rule_in_subprocess():
         want = 8 * -(-i43 // ncu) < 3 * -(-4 * i43 // ncu)
         assert bool(pref(nimg, Hh, Ww, N)) == want, (nimg, Hh, Ww, N)
     assert pref(128, 32, 32, 256) == 1 and pref(16, 32, 32, 256) == 0          # the train step keeps F(4x4,3x3); a 16-row sampler does not
+
+
+def test_small_batch_networks_through_the_f43_kernels_in_subprocess():
+    """the golden networks again with the occupancy rule OFF (VD_WINO43_OCC=0, read once per process): the B = 2 CIFAR-10 / B = 1 CelebA
+    networks and the tiny ones then run every layer the F(4x4,3x3) forward / input-gradient / weight-gradient kernels serve -- the kernels
+    of the B = 128 step -- against the same reference fixtures and bounds."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-s", "--no-header", "-p", "no:cacheprovider",
-                        "-k", "test_full_size_unet_vs_golden"], env=dict(os.environ, VD_WINO43_OCC="1"), capture_output=True, text=True,
-                       timeout=1200)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+                        "-k", "test_full_size_unet_vs_golden or test_tiny_unet_vs_golden_and_oracle"], env=dict(os.environ, VD_WINO43_OCC="0"),
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     print("\n".join(l for l in r.stdout.splitlines() if "out err" in l))
 
 

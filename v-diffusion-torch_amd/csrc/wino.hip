@@ -1184,14 +1184,6 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
         const int dty = (TWS == 16) ? 0 : (TWS == 8 ? (ks >> 1) : ks);
         const int dtx0 = (TWS == 16) ? 4 * ks : (TWS == 8 ? 4 * (ks & 1) : 0);
         f32x2 dyv[2][2], L[3][4];
-#if defined(VD_WGRAD_EXP) && VD_WGRAD_EXP >= 4
-        {   // timing experiment: operands from registers, no LDS reads
-            f32x2 seed = {__int_as_float(0x3f800000 + lane), __int_as_float(0x3f000000 + ks)};
-            asm volatile("" : "+v"(seed));
-            for (int uv = 0; uv < 4; ++uv) dyv[uv >> 1][uv & 1] = seed;
-            for (int pr = 0; pr < 3; ++pr) for (int q = 0; q < 4; ++q) L[pr][q] = seed;
-        }
-#else
 #pragma unroll
         for (int uv = 0; uv < 4; ++uv) dyv[uv >> 1][uv & 1] = *reinterpret_cast<const f32x2*>(sb + dbase + (uv * 16 + 4 * ks) * 256);
 #pragma unroll
@@ -1201,7 +1193,6 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
                 const int C = ((2 * dty + pr) * 2 + (q & 1)) * P + dtx0 + (q >> 1);
                 L[pr][q] = *reinterpret_cast<const f32x2*>(sb + ((C & 1) ? xb_odd : xb_even) + C * 256);
             }
-#endif
         if (do_bias) bsum += (dyv[0][0] + dyv[0][1]) + (dyv[1][0] + dyv[1][1]);
         // A dY A^T restricted to this wave's rows a; |coefficients| only (signs: epilogue)
         f32x2 m[2][2], tr[2][4];
@@ -1220,13 +1211,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
         f32x2 A4[2][4], V[2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-#if defined(VD_WGRAD_EXP) && VD_WGRAD_EXP >= 3
-            A4[a][0] = m[a][0]; A4[a][1] = m[a][1]; A4[a][2] = m[a][0]; A4[a][3] = m[a][1];
-            V[a][0] = tr[a][0]; V[a][1] = tr[a][1]; V[a][2] = tr[a][2]; V[a][3] = tr[a][3];
-#else
             A4[a][0] = m[a][0]; A4[a][1] = m[a][0] + m[a][1]; A4[a][2] = m[a][0] - m[a][1]; A4[a][3] = m[a][1];
             V[a][0] = tr[a][0] - tr[a][2]; V[a][1] = tr[a][1] + tr[a][2]; V[a][2] = tr[a][2] - tr[a][1]; V[a][3] = tr[a][1] - tr[a][3];
-#endif
         }
         __builtin_amdgcn_sched_barrier(0x0180 | 0x0004 | 0x0010 | 0x0020 | 0x0040 | 0x0200);     // (VALU and MFMA stay on their sides)
 #pragma unroll
@@ -1248,12 +1234,6 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
             const int buf = (st - st_begin) & 1;
             const unsigned char* sb = smem + buf * WG_STAGE_BYTES;
             // the two waves of a SIMD issue their DMA bursts half a stage apart (see wino_conv_kernel)
-#if defined(VD_WGRAD_EXP) && VD_WGRAD_EXP >= 1
-            kstep(sb, 0); kstep(sb, 1); kstep(sb, 2); kstep(sb, 3);         // timing experiment: no DMA (stale stage)
-#if VD_WGRAD_EXP < 2
-            __syncthreads();
-#endif
-#else
             if (ah == 0) issue(st + 1, buf ^ 1, st + 1 < st_end);
             kstep(sb, 0);
             kstep(sb, 1);
@@ -1262,7 +1242,6 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WgradArgs p) {
             kstep(sb, 3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-#endif
         }
     }
 

@@ -59,6 +59,7 @@ struct Args43 {
     const float* bias; const float* res; long long ldr;
     float* stats;                             // [nimg][chunks_per_img][2][N] or NULL: chunk = the pixels one work item holds of one image
     int chunks_per_img;                       // 1 (32x32, 16x16) or H/16 (64 wide)
+    unsigned long long* probe;                // -DVD_PROBES builds only (vd_wino43_set_probe): 16 x u64 per (workgroup, wave, item round < 4)
 };
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load / store of the wave
@@ -71,49 +72,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, i
 
 // 1-D input transform B^T of F(4,3), rows {0,1,2} (HALF = 0) or {3,4,5} (HALF = 1).
 //   B^T = [4 0 -5 0 1 0 ; 0 -4 -4 1 1 0 ; 0 4 -4 -1 1 0 ; 0 -2 -1 2 1 0 ; 0 2 -1 -2 1 0 ; 0 4 0 -5 0 1]
-// The transforms run on the two channels of a lane as packed fp32 instructions (v_pk_fma_f32 / v_pk_add_f32).  A/B on MI355X against
-// scalar instructions (-DVD_W43_PACKED=0 -fno-slp-vectorize): 0.460 vs 0.464 ms at 256 -> 256 @32x32 -- no difference, the packed
-// form is kept for its instruction count.
-#ifndef VD_W43_PACKED
-#define VD_W43_PACKED 1
-#endif
-// timing experiments (WRONG results; built only by tests/probe/w43_exp.sh into scratch libraries, never into the product or the
-// probe library): 1 = no DMA inside the K loop, 2 = also no transform arithmetic, 3 = also no patch reads, 4 = also no U-fragment
-// reads, 5 = full kernel without the tile barrier, 6 = full kernel that does not wait for an item's first stage (upper bound of a cross-item prefetch)
-#ifndef VD_W43_EXP
-#define VD_W43_EXP 0
-#endif
-#if VD_W43_EXP != 0 && !defined(VD_W43_SCRATCH_BUILD)
-#error "VD_W43_EXP builds compute wrong results: only tests/probe/w43_exp.sh may build them (into scratch libraries, -DVD_W43_SCRATCH_BUILD)"
-#endif
-#ifndef VD_W43_SB
-#define VD_W43_SB 12          /* MFMA step (of 18 per K tile) the tile barrier sits in front of */
-#endif
-#ifndef VD_W43_RES_AUX
-#define VD_W43_RES_AUX 0      /* cache policy of the residual loads: 0 = default, 2 = non-temporal (A/B builds: tests/probe/r04_pass16.sh) */
-#endif
-#ifndef VD_W43_ORDER
-#define VD_W43_ORDER 0        /* work items an XCD runs together: 0 = 4 channel blocks x 8 tile groups, 1 = 8 x 4 (A/B builds) */
-#endif
-#ifndef VD_W43_UPF
-#define VD_W43_UPF 2          /* MFMA steps a U fragment is read ahead of its use (same-box A/B of 1 / 2 / 3, tests/probe/r04_pass7.sh: 2 and 3 are ~1 % ahead of 1) */
-#endif
-#ifndef VD_W43_DPS
-#define VD_W43_DPS 1          /* DMA pieces of tile kt+2 issued per step behind the barrier */
-#endif
-// (round 5, built, correct and not kept -- profiles/r05_uglobal.txt: the U fragments straight from global memory (one coalesced
-//  buffer_load_b128 per MFMA step from the packed image, ring of 3 / 6 / 9 fragments across K tiles, no U pieces in the LDS-DMA plan: -52 % LDS traffic):
-//  0.673 / 0.555 / 0.552 ms against 0.432 -- the vector-memory path delivers a wave's KiB at half the LDS rate, and eight waves ask for 144 KB per K tile.)
-// (round 5, measured and not kept -- tests/probe/r05_dma_order.sh, profiles/r05_dma_order.txt: issuing a K tile's patch pieces, the ones that can miss
-//  to HBM, a whole tile ahead and its U pieces 8 steps ahead instead of the other way round: +3 %; two pieces per step behind the barrier so that
-//  10 of the 11 pieces have a tile of lead: +8 ... +14 %.  The DMA's lead time is not what the waves wait for; bunching its issue costs.)
-// start-up skew of the persistent workgroups: equal work items keep all 256 CUs in phase, so every item boundary is one chip-wide burst
-// of residual reads and output writes (FINDINGS round 4: the residual costs 15 % of a forward launch).  Workgroup w of an XCD sleeps
-// ((w >> 3) % NPH) * SLEEPS * ~3.7 us before its first item (s_sleep 127 = 8128 cycles): NPH phases that stay apart for the whole launch.
-// (round 5, measured and NOT kept -- tests/probe/r05_skew.sh, profiles/r05_skew.txt, FINDINGS round 5: a start-up skew of the persistent
-//  workgroups, 2 / 4 / 8 phases up to 3.7 ... 26 us apart, so that the item-boundary bursts of residual reads and output writes of the 256 CUs
-//  do not coincide: 0.471-0.483 ms against 0.478 at 256 -> 256 @32x32 with residual, i.e. nothing; one static s_setprio 1 for waves 4-7:
-//  +1.5 %.  The CUs being in phase is not what the residual costs.)
+// The transforms run on the two channels of a lane as packed fp32 instructions (v_pk_fma_f32 / v_pk_add_f32); measured against scalar
+// instructions twice (round 3: 0.460 vs 0.464 ms at 256 -> 256 @32x32; round 6, tests/probe/mfma_valu_fill.hip: a lump of packed
+// instructions costs the SIMD 5.1 cycles each beside v_mfma_f32_16x16x4_f32, a lump of plain ones 2.6 -- the same per element).
+//
+// What the K loop's time is made of (round 6: profiles/r06_wino43_ktile_timeline.txt, FINDINGS.md): on gfx950 the fp32 matrix
+// instruction and vector instructions of EITHER wave of a SIMD exclude each other, so a K tile costs 144 x 32 matrix cycles plus
+// every transform instruction; A/B builds of this loop that spread the transforms over the MFMA gaps (+3 %), aligned the two waves'
+// transform lumps with extra barriers (+-1 %), skewed the workgroups, changed the DMA order or lead, read U from global memory or
+// changed the scheduler strategy (rounds 4-5) all measured flat or slower.  The constants below are what those A/B builds kept.
+constexpr int SB_STEP = 12;                   // MFMA step (of 18 per K tile) the tile barrier sits in front of
+constexpr int U_AHEAD = 2;                    // MFMA steps a U fragment is read ahead of its use (1 / 2 / 3 measured: 2 and 3 ~1 % ahead of 1)
 // DY: the dyadic point set {0, +-3/4, +-3/2, inf} of the forward pass (the rows of bt6 below) instead of the classic {0, +-1, +-2, inf}
 template <int HALF, bool DY, typename T>
 __device__ __forceinline__ void bt_half(const T (&d)[6], T& o0, T& o1, T& o2) {
@@ -166,34 +135,9 @@ __device__ __forceinline__ void bt_full(const T (&r)[6], T (&v)[6]) {
 }
 // the two channels of a lane: f32x2 in, transform per channel (scalar build) or on the pair (packed build)
 template <int HALF, bool DY>
-__device__ __forceinline__ void bt_half2(const f32x2 (&d)[6], f32x2& o0, f32x2& o1, f32x2& o2) {
-#if VD_W43_PACKED
-    bt_half<HALF, DY, f32x2>(d, o0, o1, o2);
-#else
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float dj[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
-        float a, b, c;
-        bt_half<HALF, DY, float>(dj, a, b, c);
-        o0[j] = a; o1[j] = b; o2[j] = c;
-    }
-#endif
-}
+__device__ __forceinline__ void bt_half2(const f32x2 (&d)[6], f32x2& o0, f32x2& o1, f32x2& o2) { bt_half<HALF, DY, f32x2>(d, o0, o1, o2); }
 template <bool DY>
-__device__ __forceinline__ void bt_full2(const f32x2 (&r)[6], f32x2 (&v)[6]) {
-#if VD_W43_PACKED
-    bt_full<DY, f32x2>(r, v);
-#else
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float rj[6] = {r[0][j], r[1][j], r[2][j], r[3][j], r[4][j], r[5][j]};
-        float vj[6];
-        bt_full<DY, float>(rj, vj);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) v[b][j] = vj[b];
-    }
-#endif
-}
+__device__ __forceinline__ void bt_full2(const f32x2 (&r)[6], f32x2 (&v)[6]) { bt_full<DY, f32x2>(r, v); }
 
 // TWT = tiles per image row (8: 32-wide images, 16: 64-wide images, 4: 16x16 images, four of them per item)
 // 16x16 images: the item's patch image stacks its four images vertically with ONE shared zero row between neighbours (rows 17 i are the
@@ -226,6 +170,17 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
     const int tg = wave & 3;
     const int nkt = p.K / KT;
     const int G = gridDim.x;
+    // phase stamps of the probe library (tests/probe/w43_phases.py): slot s of item round n of this wave; no code in the product build
+    int probe_n = 0;
+    auto stamp = [&](int slot) {
+        if (VD_PROBE_BUILD && p.probe && probe_n < 4) {
+            const unsigned long long t = slot == 12 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.probe[(((long long)blockIdx.x * 8 + wave) * 4 + probe_n) * 16 + slot] = t;
+        }
+    };
+    auto stamp_val = [&](int slot, unsigned long long v) {
+        if (VD_PROBE_BUILD && p.probe && probe_n < 4 && lane == 0) p.probe[(((long long)blockIdx.x * 8 + wave) * 4 + probe_n) * 16 + slot] = v;
+    };
 
     // ---- DMA plan of this wave.  Patch pieces: granule wave & 1, slot groups (wave >> 1) + 4 j; U pieces wave + 8 j (linear copy).
     constexpr int APL = (NPG + 3) / 4;
@@ -278,10 +233,10 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
         }
     };
     constexpr int NPIECE = 5 + APL;
-    // the tile barrier sits in front of MFMA step SB of 18; the NAFTER steps behind it carry the row pass of the next tile and DPS DMA
-    // pieces each of the tile after that
-    constexpr int SB = VD_W43_SB, NAFTER = 18 - SB, DPS = VD_W43_DPS, PAFTER = NAFTER * DPS;
-    constexpr int UPF = VD_W43_UPF;
+    // the tile barrier sits in front of MFMA step SB of 18; the NAFTER steps behind it carry the row pass of the next tile and one DMA
+    // piece each of the tile after that
+    constexpr int SB = SB_STEP, NAFTER = 18 - SB, PAFTER = NAFTER;
+    constexpr int UPF = U_AHEAD;
     static_assert(PAFTER <= NPIECE && NPIECE - PAFTER <= SB, "DMA schedule does not fit the tile");
 
     // ---- LDS read addresses (floats): patch position (pr, q) of this lane's tile, channels {2 lq, 2 lq + 1}
@@ -300,15 +255,6 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
         int t = n * G + (int)blockIdx.x;
         if ((G & 7) == 0 && (n + 1) * G <= p.nitems) t = n * G + ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
         if (t >= p.nitems) return false;
-#if VD_W43_ORDER == 1
-        // (A/B build only: 8 channel blocks x 4 tile groups per XCD -- every tile group's patch stream stays in ONE L2, every XCD streams the
-        //  U images of 8 blocks.  Measured against the 4 x 8 order below: tests/probe/r04_pass12.sh, FINDINGS round 4)
-        if ((p.ncb & 7) == 0 && (ngrp & 3) == 0) {
-            const int c = t >> 5, i = t & 31, ncg = p.ncb >> 3;
-            cb = (c % ncg) * 8 + (i & 7); grp = (c / ncg) * 4 + (i >> 3);
-            return true;
-        }
-#endif
         if ((p.ncb & 3) == 0 && (ngrp & 7) == 0) {
             const int c = t >> 5, i = t & 31, ncg = p.ncb >> 2;
             cb = (c % ncg) * 4 + (i & 3); grp = (c / ncg) * 8 + (i >> 2);
@@ -329,34 +275,47 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr) {
                     if ((HALF == 0 && pr == 5) || (HALF == 1 && pr == 0)) d[pr] = f32x2{0.f, 0.f};
-                    else if (VD_W43_EXP >= 3 && VD_W43_EXP <= 4) d[pr] = f32x2{(float)pr, (float)q};
                     // (volatile: keeps each read a ds_read_b64 -- banks (a/4) mod 64, 32-lane groups, conflict-free on this image.  Left to
                     //  itself hipcc pairs them into ds_read2_b64, which is served in 16-lane groups on 32 banks at half the rate: the two
                     //  tile rows of a wave then collide 2-way.  PMC round 3: SQ_LDS_BANK_CONFLICT 2.7e7 per launch, 0 in every other kernel)
                     else d[pr] = *(const volatile __attribute__((address_space(3))) f32x2*)((const __attribute__((address_space(3))) float*)sa + poff(pr, q));
                 }
-                if (VD_W43_EXP >= 2 && VD_W43_EXP <= 4) { Rn[0][q] = d[1]; Rn[1][q] = d[2]; Rn[2][q] = d[3]; }
-                else bt_half2<HALF, FWD>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
+                bt_half2<HALF, FWD>(d, Rn[0][q], Rn[1][q], Rn[2][q]);
             }
         };
-        int cb = 0, grp = 0;
-        if (QUAD) offsets(0);
-        for (int n = 0; item_of(n, cb, grp); ++n) {
-            if (QUAD) xitem = p.x + (long long)grp * (4 * 16 * 16) * p.ldx;
-            else { offsets(grp); xitem = p.x + (long long)(grp / p.items_per_img) * p.H * p.W * p.ldx; }
+        // an item's FIRST stage goes out before the item starts: for the first item here, for every later one from inside the previous item's
+        // epilogue, as soon as the exchange area that overlays stage 0 has been read (round 6: the stamps of tests/probe/w43_phases.py put 9-13
+        // thousand cycles per item -- 4-5 % -- on the wait for this DMA when it was issued at the item's top, behind the output stores)
+        auto first_stage = [&](int cbx, int grpx) {
+            if (QUAD) xitem = p.x + (long long)grpx * (4 * 16 * 16) * p.ldx;
+            else { offsets(grpx); xitem = p.x + (long long)(grpx / p.items_per_img) * p.H * p.W * p.ldx; }
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i) issue_piece(i, 0, 0, cb);
+            for (int i = 0; i < NPIECE; ++i) issue_piece(i, 0, 0, cbx);
+        };
+        int cb = 0, grp = 0, cb_next = 0, grp_next = 0;
+        if (QUAD) offsets(0);
+        bool have = item_of(0, cb, grp);
+        if (have) first_stage(cb, grp);
+        for (int n = 0; have; ++n) {
+            probe_n = n;
+            stamp(0); stamp(12);
+            unsigned long long t_vm = 0, t_bar = 0;
             f32x4 acc[18][2];
 #pragma unroll
             for (int x = 0; x < 18; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            if (VD_W43_EXP != 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (EXP 6: what would hiding the first stage's latency buy?)
-            if (VD_W43_EXP != 6) __syncthreads(); else lds_barrier();
+            // the first stage has landed: everything older than this wave's 16 output stores of the previous item (vmcnt counts in issue order;
+            // a wave that also wrote statistics waits for one store more)
+            if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            lds_barrier();
+            stamp(1);
             if (nkt > 1) {
 #pragma unroll
                 for (int i = 0; i < PAFTER; ++i) issue_piece(i, 1, 1, cb);
             }
             f32x2 R[3][6];
             rowpass(smem + pbase, R, 0, 6);
+            stamp(2);
             // K loop.  Tile kt lives in stage kt & 1.  ONE barrier per tile, in front of step SB of its 18 MFMA steps, with the
             // U fragments of steps SB..17 already in registers: behind it stage kt is dead (the patch of tile kt was consumed
             // during tile kt-1) and stage kt+1 has landed, so the remaining three steps run beside the row pass of tile kt+1 --
@@ -375,28 +334,31 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     f32x2 V[6];
-                    if (VD_W43_EXP >= 2 && VD_W43_EXP <= 4) {
-#pragma unroll
-                        for (int b = 0; b < 6; ++b) V[b] = R[a][b];
-                    } else bt_full2<FWD>(R[a], V);
+                    bt_full2<FWD>(R[a], V);
 #pragma unroll
                     for (int b = 0; b < 6; ++b) {
                         const int xl = 6 * a + b;
                         if (xl == SB) {
 #pragma unroll
                             for (int e = 0; e < NAFTER; ++e) ufl[e] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + SB + e) * 256);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            if (VD_W43_EXP != 5) __syncthreads();
+                            if (VD_PROBE_BUILD && p.probe) {        // (probe library: cycles waiting for this wave's DMA / parked at the barrier)
+                                const unsigned long long ta = __builtin_amdgcn_s_memtime();
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                const unsigned long long tb = __builtin_amdgcn_s_memtime();
+                                __syncthreads();
+                                const unsigned long long tc = __builtin_amdgcn_s_memtime();
+                                t_vm += tb - ta; t_bar += tc - tb;
+                            } else {
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                __syncthreads();
+                            }
                         }
-                        if (xl + UPF < SB && VD_W43_EXP != 4) uf[(xl + UPF) % (UPF + 1)] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + UPF) * 256);
+                        if (xl + UPF < SB) uf[(xl + UPF) % (UPF + 1)] = *reinterpret_cast<const f32x4*>(su + (18 * HALF + xl + UPF) * 256);
                         // DMA of tile kt+1: pieces PAFTER .. NPIECE-1 in the first steps of this tile (pieces 0 .. PAFTER-1 went out behind
                         // the barrier of tile kt-1); DMA of tile kt+2: pieces 0 .. PAFTER-1 behind this tile's barrier
-                        if (xl + PAFTER < NPIECE && !(VD_W43_EXP >= 1 && VD_W43_EXP <= 4)) { if (n1) issue_piece(xl + PAFTER, kt + 1, st ^ 1, cb); }
+                        if (xl + PAFTER < NPIECE) { if (n1) issue_piece(xl + PAFTER, kt + 1, st ^ 1, cb); }
                         if (xl >= SB) {
-                            if (n2 && !(VD_W43_EXP >= 1 && VD_W43_EXP <= 4)) {
-#pragma unroll
-                                for (int e = 0; e < DPS; ++e) issue_piece((xl - SB) * DPS + e, kt + 2, st, cb);
-                            }
+                            if (n2) issue_piece(xl - SB, kt + 2, st, cb);
                             rowpass(san, Rn, (6 * (xl - SB)) / NAFTER, (6 * (xl - SB + 1)) / NAFTER);     // (last tile: a stale stage, result unused)
                         }
                         const f32x4 u = xl < SB ? uf[xl % (UPF + 1)] : ufl[xl < SB ? 0 : xl - SB];
@@ -412,7 +374,9 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) R[a][q] = Rn[a][q];
             }
+            stamp(3);
             __syncthreads();                                        // every wave is through its last three steps: the stages are dead
+            stamp(4);
 
             // ---------------- epilogue: dx = A^T M A      A^T = [1 1 1 1 1 0 ; 0 1 -1 2 -2 0 ; 0 1 1 4 4 0 ; 0 1 -1 8 -8 1]
             // this wave holds rows a = 3 HALF + a' of M for both channel blocks: column pass in registers, then its partial row
@@ -480,10 +444,12 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                             for (int v = 0; v < 4; ++v) {
                                 RV[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
                                 if (p.res) RV[u][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rrs, (int)(((pixr + (unsigned)(u * p.W + v)) * (unsigned)p.ldr + n0r) * 4u), 0, VD_W43_RES_AUX));
+                                                          rrs, (int)(((pixr + (unsigned)(u * p.W + v)) * (unsigned)p.ldr + n0r) * 4u), 0, 0));
                             }
                     }
+                    stamp(5);
                     lds_barrier();                                  // (the residual loads stay in flight across it)
+                    stamp(6);
                 }
             }
             {
@@ -493,11 +459,20 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) Y[u][v] += xch[(partner * 16 + 4 * u + v) * 64 + lane_e];
             }
+            // the exchange area is read: the NEXT item's first stage may overwrite the part of it that overlays stage 0 -- it streams in under
+            // the rest of this epilogue (bias / residual / statistics / the 16 output stores) instead of being waited for at the next item's top
+            const int cb_cur = cb, grp_cur = grp;
+            const bool have_next = item_of(n + 1, cb_next, grp_next);
+            lds_barrier();
+            stamp(7);
+            if (have_next) first_stage(cb_next, grp_next);
+            __builtin_amdgcn_sched_barrier(0);                      // (the output stores below stay behind the DMA issue: the next item waits with vmcnt(16))
+            asm volatile("" ::: "memory");
             {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const int img = QUAD ? 4 * grp + (tyl_e >> 2) : grp / p.items_per_img;
-                const int part = QUAD ? 0 : grp - img * p.items_per_img;
-                const int n0 = cb * TN + 16 * HALF + 4 * lq_e;
+                const int img = QUAD ? 4 * grp_cur + (tyl_e >> 2) : grp_cur / p.items_per_img;
+                const int part = QUAD ? 0 : grp_cur - img * p.items_per_img;
+                const int n0 = cb_cur * TN + 16 * HALF + 4 * lq_e;
                 const int y0 = QUAD ? 4 * (tyl_e & 3) : 4 * (NTR * part + tyl_e), x0 = 4 * tx_e;
                 const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.y + (QUAD ? 0LL : (long long)img * p.H * p.W * p.ldy));
                 const unsigned ldy_u = (unsigned)p.ldy;
@@ -540,12 +515,12 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                         __builtin_amdgcn_raw_buffer_store_b128(wv, yrs, (int)vo, 0, 0);
                     }
             }
-            lds_barrier();                                          // the exchange area is read: the next item's DMA may overwrite it (the output
-                                                                    // stores drain behind the barrier, under the next item's first-stage DMA)
+            stamp(8);
             if (FWD && p.stats) {
                 // partial sums of the item: one chunk per image it holds -- the four tile-group waves of a xi half together (one 32x32
                 // image, 16 rows of a 64-wide one) or one wave each (QUAD: a wave's 16 tiles are one 16x16 image).  Fixed order, no atomics.
-                // (read before this wave issues the next item's DMA; the other waves' DMA into this area waits behind the next barrier)
+                // (the area lies in stage 1, which the next item's first stage does not touch; its tile-1 DMA waits behind the next item's first barrier)
+                lds_barrier();
                 const float* sarea = smem + 8 * 16 * 64 * 4;
                 const int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 if (tid_e < (QUAD ? 256 : 64)) {
@@ -555,11 +530,13 @@ __global__ __launch_bounds__(THREADS) void wino43_conv_kernel(const Args43 p) {
                     if (QUAD) v = sarea[((4 * h + tgq) * 4 + q4) * 8 + 4 * st + j];
                     else v = (sarea[((4 * h + 0) * 4 + q4) * 8 + 4 * st + j] + sarea[((4 * h + 1) * 4 + q4) * 8 + 4 * st + j]) +
                              (sarea[((4 * h + 2) * 4 + q4) * 8 + 4 * st + j] + sarea[((4 * h + 3) * 4 + q4) * 8 + 4 * st + j]);
-                    const int img = QUAD ? 4 * grp + tgq : grp / p.items_per_img;
-                    const int chunk = QUAD ? 0 : grp - img * p.items_per_img;
-                    p.stats[(((long long)img * p.chunks_per_img + chunk) * 2 + st) * p.N + cb * TN + ch] = v;
+                    const int img = QUAD ? 4 * grp_cur + tgq : grp_cur / p.items_per_img;
+                    const int chunk = QUAD ? 0 : grp_cur - img * p.items_per_img;
+                    p.stats[(((long long)img * p.chunks_per_img + chunk) * 2 + st) * p.N + cb_cur * TN + ch] = v;
                 }
             }
+            stamp(9); stamp_val(10, t_vm); stamp_val(11, t_bar);
+            cb = cb_next; grp = grp_next; have = have_next;
         }
     };
     if ((wave >> 2) == 0) run(std::integral_constant<int, 0>{});
@@ -660,24 +637,11 @@ __device__ __forceinline__ void a6(const f32x4 (&y)[4], f32x4 (&o)[6]) {
     o[5] = y[3];
 }
 
-// V / dM layout: K-blocked [T/16][36][16][C] (1: a transform block's 36 planes land in one contiguous run, the grouped GEMMs step through K
-// blocks: vd_gemm_grouped_wgrad_kblk) or plane-major [36][T][C] (0: same-box A/B builds only, tests/probe/r04_pass4.sh)
-#ifndef VD_W43_KBLOCK
-#define VD_W43_KBLOCK 1
-#endif
-// the transform pass writes V / dM once, the grouped GEMMs read them back right after: PLAIN stores.  Non-temporal ones (VD_W43_NT=1) measured
-// 8-10 % slower (0.164-0.173 vs 0.152 ms at 256 -> 256 @32x32, same-box A/B tests/probe/r04_pass15.sh) -- unlike the optimizer pass and the
-// GroupNorm backward, whose streams nobody reads back soon
-#ifndef VD_W43_NT
-#define VD_W43_NT 0
-#endif
-__device__ __forceinline__ void st_once(float* p, f32x4 v) {
-#if VD_W43_NT
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-#else
-    *reinterpret_cast<f32x4*>(p) = v;
-#endif
-}
+// V / dM layout: K-blocked [T/16][36][16][C]: a transform block's 36 planes land in one contiguous run, the grouped GEMMs step through K
+// blocks (vd_gemm_grouped_wgrad_kblk).  (Plane-major [36][T][C] measured slower, round 4.)
+// The transform pass writes V / dM once, the grouped GEMMs read them back right after: PLAIN stores (non-temporal ones measured 8-10 % slower,
+// 0.164-0.173 vs 0.152 ms at 256 -> 256 @32x32 -- unlike the optimizer pass and the GroupNorm backward, whose streams nobody reads back soon).
+__device__ __forceinline__ void st_once(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 struct WgT43 {
     const float* x; long long ldx; const float* dy; long long lddy;
     float* V; float* dM;                       // [T/16][36][16][Cin], [T/16][36][16][Cout]: blocks of 16 tiles, the 36 planes of a block adjacent
@@ -715,8 +679,7 @@ __global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43
             bt6(col, o);                                            // V[a][b] = sum_p B^T[a][p] R[p][b]
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                st_once(p.V + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
-                                             : ((long long)(6 * a + b) * p.T + tile)) * p.Cin + c4, o[a]);
+                st_once(p.V + ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15)) * p.Cin + c4, o[a]);
         }
     } else {
         if (c4 >= p.Cout) return;
@@ -736,8 +699,7 @@ __global__ __launch_bounds__(256) void wino43_wgrad_transform_kernel(const WgT43
             a6(col, o);                                             // dM[a][b] = sum_u A[a][u] R[u][b]
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                st_once(p.dM + (VD_W43_KBLOCK ? ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15))
-                                              : ((long long)(6 * a + b) * p.T + tile)) * p.Cout + c4, o[a]);
+                st_once(p.dM + ((long long)((tile >> 4) * 36 + 6 * a + b) * 16 + (tile & 15)) * p.Cout + c4, o[a]);
         }
     }
 }
@@ -869,6 +831,11 @@ Wg43Plan wg43_plan(int nimg, int H, int W, int Cin, int Cout) {
 }
 
 thread_local int g_last43 = 0;
+#ifdef VD_PROBES
+unsigned long long* g_probe43 = nullptr;   // probe library only (vd_wino43_set_probe)
+#else
+constexpr unsigned long long* g_probe43 = nullptr;
+#endif
 thread_local int g_last43w = 0;        // split-K slabs of the calling thread's last vd_conv3x3_wgrad_wino43 launch
 
 }  // namespace
@@ -918,6 +885,7 @@ extern "C" int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const floa
     const long long items = (long long)a.ngrp * a.ncb;
     VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_dgrad_wino43: too many work items");
     a.nitems = (int)items;
+    a.probe = g_probe43;
     const int ncu = vd_persistent_cus();      // (one workgroup per CU, minus the CUs reserved for other streams: vd_set_reserved_cus)
     const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(THREADS);
     hipStream_t st = (hipStream_t)stream;
@@ -932,6 +900,9 @@ extern "C" int vd_conv3x3_dgrad_wino43(const float* dy, int64_t lddy, const floa
 /* tiles per row (4 / 8 / 16) of the calling thread's last vd_conv3x3_dgrad_wino43 (positive) or vd_conv3x3_wino43_fwd (negative) launch
  * = the instantiation wino43_conv_kernel<TWT, FWD> */
 extern "C" int vd_wino43_last_kernel(void) { return g_last43; }
+#ifdef VD_PROBES
+extern "C" int vd_wino43_set_probe(unsigned long long* buf) { g_probe43 = buf; return 0; }
+#endif
 
 extern "C" int vd_wino43_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* U43, void* stream) {
     VD_REQUIRE(w_oihw && U43 && Cout % KT == 0 && Cin % TN == 0, "vd_wino43_pack: needs Cout %% 8 == 0 and Cin %% 32 == 0");
@@ -985,6 +956,7 @@ extern "C" int vd_conv3x3_wino43_fwd(const float* xin, int64_t ldx, const float*
     const long long items = (long long)a.ngrp * a.ncb;
     VD_REQUIRE(items < (1LL << 30), "vd_conv3x3_wino43_fwd: too many work items");
     a.nitems = (int)items;
+    a.probe = g_probe43;
     const int ncu = vd_persistent_cus();
     const dim3 grid((unsigned)(items < ncu ? items : ncu)), blk(THREADS);
     hipStream_t st = (hipStream_t)stream;
@@ -1053,11 +1025,11 @@ static int wgrad43_impl(const float* xin, int64_t ldx, const float* dy, int64_t 
     if (phases & 2) {
         const float* A[36]; const float* B[36]; float* C[36]; float* colsum[36];
         for (int e = 0; e < 36; ++e) {
-            A[e] = dM + (size_t)e * (VD_W43_KBLOCK ? 16 : g.T) * Cout; B[e] = V + (size_t)e * (VD_W43_KBLOCK ? 16 : g.T) * Cin;
+            A[e] = dM + (size_t)e * 16 * Cout; B[e] = V + (size_t)e * 16 * Cin;
             C[e] = dU + (size_t)e * Cout * Cin; colsum[e] = cs + (size_t)e * Cout;
         }
         const int rc = vd_gemm_grouped_wgrad_kblk(A, B, C, colsum, 36, Cout, Cin, g.T, Cout, Cin, Cin, g.S, gws, g.gemm_bytes, stream,
-                                                  VD_W43_KBLOCK ? 36LL * 16 * Cout : 0, VD_W43_KBLOCK ? 36LL * 16 * Cin : 0,
+                                                  36LL * 16 * Cout, 36LL * 16 * Cin,
                                                   (long long)Cout * Cin >= FUSED_FINISH_MIN ? 1 : 0);
         if (rc) return rc;
         g_last43w = g.S;

@@ -128,7 +128,7 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES)
 # extra entry points of libvdiff_hip_probe.so (built with -DVD_PROBES; tests/probe/*.py load it through VDIFF_HIP_LIB): bound when
 # the loaded library has them, absent from the product library
-PROBE_EXPORTS = {"vd_wino_set_probe": (C.c_int, [_vp])}
+PROBE_EXPORTS = {"vd_wino_set_probe": (C.c_int, [_vp]), "vd_wino43_set_probe": (C.c_int, [_vp])}
 
 _lib = None
 
