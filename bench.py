@@ -33,6 +33,15 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2517.0         # MI355X_MICROARCH.md: dense bf16 MFMA
+# ceiling of the split-operand GEMM forms (gemm_split_kernel): every fp32 product = six bf16 piece products on the 16-bit matrix cores
+PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+
+
+def kernel_peak(kernel_name):
+    """the matrix-core ceiling a kernel is priced against, in fp32-equivalent TFLOP/s: 157.3 for the fp32 MFMA instructions, dense bf16 / 6
+    = 419.5 for the split-operand (bf16x3) forms of the tile engine"""
+    return PEAK_SPLIT_TFLOPS if "gemm_split" in kernel_name else PEAK_FP32_MFMA_TFLOPS
 CIFAR = dict(in_channels=3, hid_channels=256, out_channels=3, ch_multipliers=[1, 1, 1], num_res_blocks=3,
              apply_attn=[False, True, True], drop_rate=0.2, num_heads=1, num_classes=10, multitags=False)
 FWD_GFLOP_PER_IMG = 37.64              # SURVEY 8d: matmul-class FLOPs of one CIFAR UNet forward
@@ -234,7 +243,7 @@ def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, ba
         ds = float(tmax.item())
     # share of the algorithmic FLOPs the matrix cores execute in THIS sampler, from the launches two reverse steps record (each launch
     # carries the 2*M*N*K of the op it implements; executed_share() says what its kernel really multiplies)
-    exec_frac, rec_gflop = W["fwd_exec_frac"], None
+    exec_frac, rec_gflop, dominant, table = W["fwd_exec_frac"], None, None, None
     if rank == 0:
         from v_diffusion import _hip
         xt = torch.randn((SB, 3, RES, RES), device=device)
@@ -248,9 +257,30 @@ def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, ba
         fe = sum(r[1] * executed_share(r[0]) for r in rec if not r[0].startswith("hbm:"))
         if fl > 0:
             exec_frac, rec_gflop = fe / fl, fl / 2 / (2 * SB) / 1e9      # recorded algorithmic GFLOP per UNet row (fwd_gflop)
+        agg = {}
+        for name, work, e0, e1 in rec:
+            if name.startswith("hbm:"):
+                continue
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += work; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        if agg:
+            tot = sum(v[1] for v in agg.values())
+            table = {k: {"tflops": round(executed_share(k) * v[0] / v[1] / 1e12, 2), "peak": kernel_peak(k),
+                         "frac": round(executed_share(k) * v[0] / v[1] / 1e12 / kernel_peak(k), 4), "ms_per_reverse_step": round(v[1] / 2 * 1e3, 3),
+                         "launches_per_reverse_step": v[2] // 2, "avg_launch_ms": round(v[1] / v[2] * 1e3, 4)}
+                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10] if v[1] > 0}
+            dk = max(agg, key=lambda k: agg[k][1])
+            dv = agg[dk]
+            dominant = {"kernel": dk, "avg_launch_ms": round(dv[1] / dv[2] * 1e3, 4), "launches_per_reverse_step": dv[2] // 2,
+                        "achieved": round(executed_share(dk) * dv[0] / dv[1] / 1e12, 2), "peak": kernel_peak(dk), "unit": "TFLOP/s",
+                        "frac": round(executed_share(dk) * dv[0] / dv[1] / 1e12 / kernel_peak(dk), 4),
+                        "algorithmic_tflops": round(dv[0] / dv[1] / 1e12, 2), "share_of_matmul_time": round(dv[1] / tot, 3)}
     model.train()
     alg = T * 2 * W["fwd_gflop"] * SB / ds / 1e3                      # algorithmic TFLOP/s (2 x T x forward)
     exe = alg * exec_frac
+    tname = "r06_sampler_traffic.json" if RES == 32 else "r06_celeba_sampler_traffic.json"
+    if not os.path.exists(os.path.join(ROOT, "profiles", tname)):
+        tname = None
     return {"metric": f"ddim{T}_cfg_samples_per_sec", "value": round(world * SB / ds, 2), "unit": "images/s",
             "seconds_per_batch": round(ds, 3), "batch_per_gpu": SB, "unet_rows_per_step": 2 * SB, "w_guide": float(diffusion.w_guide),
             "roofline": {"bound": "mfma", "achieved": round(exe, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -259,8 +289,13 @@ def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, ba
                          "frac_vs_direct_roofline": round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                          "executed_share_of_algorithmic_flops": round(exec_frac, 4),
                          "recorded_gflop_per_unet_row": None if rec_gflop is None else round(rec_gflop, 2),
-                         "note": "achieved = MFMA FLOPs executed: the share comes from the launches two reverse steps of this run record "
-                                 "(Winograd convolutions execute 4/9 of their algorithmic FLOPs); algorithmic_tflops = SURVEY 8d count"},
+                         "dominant_kernel": dominant, "top_kernels": table,
+                         "kernel_table": "profiles/r06_sampler_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tests/probe/sample_only.py, the same sampler call)",
+                         "traffic_table": None if tname is None else f"profiles/{tname}",
+                         "note": "achieved = MFMA FLOPs executed over the whole sampler call (wall time, launch gaps included): the share comes from the "
+                                 "launches two reverse steps of this run record (F(4x4,3x3) convolutions execute 1/4 of their algorithmic FLOPs, F(2x2,3x3) "
+                                 "ones 4/9); algorithmic_tflops = SURVEY 8d count; dominant_kernel / top_kernels: HIP events around every launch of those "
+                                 "two steps, each kernel against its own ceiling (157.3 fp32 MFMA, 419.5 split-operand GEMM forms)"},
             "finite": bool(torch.isfinite(out).all())}
 
 
@@ -375,8 +410,16 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
         alg_tf = fl / tt_ / 1e12
         step_alg = sum(v[0] for v in agg.values()) / 2                      # algorithmic FLOPs of one step, as launched
         step_exe = sum(v[0] * executed_share(k) for k, v in agg.items()) / 2
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(exe * alg_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(exe * alg_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        # the step's executed work by instruction class, each against its own ceiling: fp32 MFMA (Winograd convolutions, fused attention, 64-row
+        # tiles) and the split-operand (bf16x3) forms of the tile engine; roofline_ms = the time the launches would take at their ceilings
+        cls = {"fp32_mfma": [0.0, 0.0], "bf16x3_split": [0.0, 0.0]}
+        for k, v in agg.items():
+            c = cls["bf16x3_split" if "gemm_split" in k else "fp32_mfma"]
+            c[0] += v[0] * executed_share(k) / 2; c[1] += v[1] / 2
+        ideal_ms = sum(c[0] / (peak * 1e12) for c, peak in ((cls["fp32_mfma"], PEAK_FP32_MFMA_TFLOPS), (cls["bf16x3_split"], PEAK_SPLIT_TFLOPS))) * 1e3
+        dom_peak = kernel_peak(dom)
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(exe * alg_tf, 2), "peak": dom_peak,
+                    "unit": "TFLOP/s", "frac": round(exe * alg_tf / dom_peak, 4), "traffic": traffic,
                     "algorithmic_tflops": round(alg_tf, 2),
                     "speedup_vs_direct_roofline": round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                     "frac_vs_direct_roofline": round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),      # SURVEY 8d's definition: algorithmic FLOPs / time / peak
@@ -392,19 +435,31 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
                     "clock_note": ("peak = 2.4 GHz figure; in-kernel clock (s_memtime / s_memrealtime beside the running kernel, "
                                    "profiles/r05_clock_by_kernel.txt): 2.37 GHz under the Winograd convolution kernels, 2.27-2.28 GHz under the "
                                    "tile-engine GEMMs, 2.33 GHz over the whole train step"),
-                    "peak_note": ("split-operand GEMM (three bf16 pieces per fp32 operand, six products on the 16-bit matrix cores): achieved counts fp32-"
-                                  "equivalent FLOPs against the fp32-MFMA peak; the form's own ceiling is the dense bf16 MFMA rate / 6 = 417 TFLOP/s, and "
-                                  "it runs power-limited at 1.88 GHz (profiles/r05_clock_split.txt)") if "gemm_split" in dom else None,
+                    "peak_note": ("every kernel is priced against its own ceiling: 157.3 TFLOP/s for the fp32 MFMA instructions, dense bf16 / 6 = "
+                                  f"{PEAK_SPLIT_TFLOPS} for the split-operand GEMM forms (three bf16 pieces per fp32 operand, six products on the 16-bit "
+                                  "matrix cores; they run power-limited at 1.88 GHz, profiles/r05_clock_split.txt)"),
                     "launches_per_step": n // 2, "avg_launch_ms": round(tt_ / n * 1e3, 4),
                     "flops_per_launch": round(exe * fl / n / 1e9, 3), "flops_unit": "GFLOP executed on the matrix cores per launch",
                     "algorithmic_flops_per_launch": round(fl / n / 1e9, 3),
                     "share_of_matmul_time": round(tt_ / total_t, 3),
-                    "all_matmul_kernels": {k: {"tflops": round(executed_share(k) * v[0] / v[1] / 1e12, 2),
+                    "all_matmul_kernels": {k: {"tflops": round(executed_share(k) * v[0] / v[1] / 1e12, 2), "peak": kernel_peak(k),
+                                               "frac": round(executed_share(k) * v[0] / v[1] / 1e12 / kernel_peak(k), 4),
                                                "algorithmic_tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / 2 * 1e3, 2),
                                                "launches_per_step": v[2] // 2} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])
                                            if v[0] > 0 or v[1] / 2 * 1e3 >= 0.05},
-                    "whole_step": {"mfma_executed_tflops": round(step_exe / (ms_per_step * 1e-3) / 1e12, 2),
-                                   "frac": round(step_exe / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "whole_step": {"frac": round(ideal_ms / ms_per_step, 4),
+                                   "frac_note": "time the step's matmul launches would take at their own ceilings / measured step time (<= 1 by construction)",
+                                   "roofline_ms": round(ideal_ms, 2),
+                                   "fp32_mfma": {"executed_gflop_per_step": round(cls["fp32_mfma"][0] / 1e9, 1), "ms_in_kernels": round(cls["fp32_mfma"][1] * 1e3, 2),
+                                                 "tflops_in_kernels": round(cls["fp32_mfma"][0] / max(cls["fp32_mfma"][1], 1e-9) / 1e12, 2),
+                                                 "peak": PEAK_FP32_MFMA_TFLOPS,
+                                                 "frac_in_kernels": round(cls["fp32_mfma"][0] / max(cls["fp32_mfma"][1], 1e-9) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                                   "bf16x3_split": {"executed_gflop_per_step": round(cls["bf16x3_split"][0] / 1e9, 1),
+                                                    "ms_in_kernels": round(cls["bf16x3_split"][1] * 1e3, 2),
+                                                    "tflops_in_kernels": round(cls["bf16x3_split"][0] / max(cls["bf16x3_split"][1], 1e-9) / 1e12, 2),
+                                                    "peak": PEAK_SPLIT_TFLOPS,
+                                                    "frac_in_kernels": round(cls["bf16x3_split"][0] / max(cls["bf16x3_split"][1], 1e-9) / 1e12 / PEAK_SPLIT_TFLOPS, 4)},
+                                   "mfma_executed_tflops": round(step_exe / (ms_per_step * 1e-3) / 1e12, 2),
                                    "algorithmic_tflops": round(3 * W["fwd_gflop"] * B / (ms_per_step * 1e-3) / 1e3, 2),
                                    "speedup_vs_direct_roofline": round(3 * W["fwd_gflop"] * B / (ms_per_step * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "launched_algorithmic_gflop_per_step": round(step_alg / 1e9, 1)}}
@@ -477,6 +532,8 @@ def main():
     ap.add_argument("--uint8-input", action="store_true", help="feed every train step a uint8 HWC batch + flip mask (the dataset's format "
                     "before the reference's CPU transforms, datasets.py:111-126) through HotPathTrainer.step_uint8")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock PyTorch-ROCm baseline leg (torch_rocm_baseline)")
+    ap.add_argument("--no-fp32-ab", action="store_true", help="skip the fp32-MFMA A/B leg (a fresh child process with VD_GEMM_SPLIT=0 after the timed region)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the 1.5 s MFMA calibration loop in front of the timed region")
     ap.add_argument("--sample-steps", type=int, default=50)
     ap.add_argument("--config", choices=["cifar10", "celeba"], default="cifar10",
                     help="cifar10 = the headline workload (BASELINE configs[1]); celeba = configs[3] as the primary line")
@@ -516,6 +573,15 @@ def main():
         torch.cuda.synchronize()
 
     B = args.batch
+    # ---- in-run clock figure (round-5 review 2e): a fixed register-only fp32 MFMA loop for 1.5 s right in front of the timed region; its in-kernel
+    # clock (s_memtime / s_memrealtime) and rate say how fast THIS box runs matrix work, so that lines from different boxes can be normalised
+    calib = None
+    if not args.no_calibration:
+        mhz, tf = _hip.mfma_calibrate(1.5)
+        calib = {"kernel": "mfma_calibrate_kernel: 256 workgroups x 8 waves, register-only v_mfma_f32_16x16x4_f32", "seconds": 1.5,
+                 "in_kernel_clock_mhz": round(mhz, 1), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                 "note": "measured on this box immediately before the timed steps; the train step itself holds 2.33 GHz on a 2.40 GHz box "
+                         "(profiles/r05_clock_by_kernel.txt) -- scale by in_kernel_clock_mhz / 2400 when comparing boxes"}
     r = run_training(wl, B, args.steps, args.warmup, device, rank, world, barrier, args.sample_steps, extras=not args.no_extras,
                      uint8_input=args.uint8_input)
     model, diffusion, labels, RES = r["model"], r["diffusion"], r["labels"], r["res"]
@@ -583,6 +649,24 @@ def main():
         except Exception as e:                      # a baseline that cannot run must not take the measured line down with it
             torch_base = {"value": None, "kind": "port on ATen/MIOpen", "baseline_only": True, "error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- the pure fp32-MFMA figure beside the headline (round-5 review 2b): VD_GEMM_SPLIT is read once per process, so a FRESH CHILD PROCESS
+    # (never a re-exec) runs the same timed region with the tile-engine GEMMs on the fp32 MFMA instructions, after every timed region here
+    fp32_ab = None
+    if rank == 0 and world == 1 and not args.no_fp32_ab and _hip.lib().vd_gemm_split_forms():
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(B),
+               "--config", wl, "--no-sample", "--no-cpu-baseline", "--no-secondary", "--no-extras", "--no-torch-baseline", "--no-fp32-ab",
+               "--no-calibration"]
+        try:
+            cp = subprocess.run(cmd, env=dict(os.environ, VD_GEMM_SPLIT="0"), capture_output=True, text=True, timeout=600)
+            jl = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+            cj = json.loads(jl[-1])
+            fp32_ab = {"env": "VD_GEMM_SPLIT=0 (tile-engine GEMMs on v_mfma_f32_*: fp32 MFMA everywhere)", "dtype": cj["dtype"],
+                       "ms_per_step": cj["ms_per_step"], "value": cj["value"], "unit": "images/s", "steps": cj["steps"], "warmup": cj["warmup"],
+                       "headline_over_fp32_mfma": round(r["value"] / cj["value"], 4)}
+        except Exception as e:
+            fp32_ab = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+
     # the arithmetic the path computes in: fp32 operands and results everywhere; Winograd convolutions and the fused attention on the fp32 MFMA
     # instructions; the tile-engine GEMMs (1x1 convolutions, linears, attention products, weight-gradient planes) by default through split
     # operands -- every fp32 value the exact sum of three bf16 pieces, six piece products on the 16-bit matrix cores, fp32 accumulation,
@@ -595,7 +679,10 @@ def main():
                 "config": {"workload": r["name"] + " full train step: q_sample+fwd+snr_trunc v-loss+bwd+grad all-reduce+clip+AdamW+EMA; "
                                        "second figure: DDIM-50 CFG w=1 sampling",
                            "global_batch": world * B, "per_gpu_batch": B, "resolution": RES, "parallelism": f"dp{world}",
-                           "final_loss": round(r["final_loss"], 5)},
+                           "final_loss": round(r["final_loss"], 5),
+                           "ddim_cfg_samples_per_sec": None if sampling is None else sampling["value"]},
+                "sampling_images_per_sec": None if sampling is None else sampling["value"],
+                "fp32_mfma_ab": fp32_ab, "calibration": calib,
                 "ms_per_step_with_loss_item": r.get("ms_per_step_with_loss_item"), "ms_fwd_bwd_only": r.get("ms_fwd_bwd_only"),
                 "hbm_peak_gib": round(hbm_peak / 2 ** 30, 2),
                 "roofline": r["roofline"], "cpu_baseline": cpu, "torch_rocm_baseline": torch_base, "sampling": sampling,

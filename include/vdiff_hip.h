@@ -40,6 +40,12 @@ const char* vd_last_error(void);
 int         vd_set_reserved_cus(int32_t n);
 int         vd_reserved_cus(void);
 
+/* Calibration loop for bench.py (no reference counterpart: a measurement aid): `blocks` workgroups of 8 waves run `iters` x 16
+ * register-only v_mfma_f32_16x16x4_f32 per wave (2048 FLOP each per wave) on operands hashed from `seed`; lane 0 of workgroup b writes
+ * stamps[2b] = shader cycles (s_memtime) and stamps[2b + 1] = 100 MHz ticks (s_memrealtime) the loop took: the in-kernel clock is their
+ * quotient x 100 MHz.  sink: one float, never written in practice. */
+int         vd_mfma_calibrate(float* sink, unsigned long long* stamps, int32_t blocks, int32_t iters, uint32_t seed, void* stream);
+
 /* ------------------------------------------------------------------ dense contractions (MFMA fp32)
  * One tile engine (v_mfma_f32_32x32x2_f32, LDS-staged, double buffered) behind every
  * matmul-shaped op of the path.  C[z][m][n] = alpha * sum_k A(z,m,k) * B(z,n,k) (+bias[n]) (+R[z][m][n]) (+C) */
@@ -148,6 +154,8 @@ int vd_wino_wgrad_last_kernel(void);
 int vd_wino_set_probe(unsigned long long* buf);
 /* the same for the F(4x4,3x3) forward and input-gradient launches -- tests/probe/w43_phases.py: 16 x uint64 per (workgroup, wave, item round < 4) */
 int vd_wino43_set_probe(unsigned long long* buf);
+/* the longest sibling wait (spin iterations, atomicMax) of the SPLIT GroupNorm-backward launches that follow -- tests/test_multigpu_path_gpu.py soak */
+int vd_gn_set_spin_probe(unsigned* buf);
 #endif
 int vd_wino_pack(const float* w_oihw, int32_t Cout, int32_t Cin, float* uf /* or NULL */, float* ud /* or NULL */, void* stream);
 /* ---- input gradient of the same convolution as Winograd F(4x4, 3x3) (csrc/wino43.hip): 36 multiplies per 4x4 output tile where

@@ -110,8 +110,8 @@ def main():
         tag = f"{mot}_{vt}"
         kl["loss_" + tag] = lr.detach().numpy()
         if tag == "v_fixed_medium":
-            names, norms, heads = grad_digest([(k, p.grad) for k, p in m.named_parameters()])
-            kl["grad_names"], kl["grad_norms"], kl["grad_heads"] = names, norms, heads
+            names, norms, heads, projs = grad_digest([(k, p.grad) for k, p in m.named_parameters()])
+            kl["grad_names"], kl["grad_norms"], kl["grad_heads"], kl["grad_projs"] = names, norms, heads, projs
     # the two terms + prediction on explicit tensors, clipped and not (what calc_all_bpd's loop body evaluates)
     gd = RefGD(ref_get_schedule("cosine", -20.0, 20.0), Tk, "v", "fixed_medium", "snr_trunc", "kl", intp_frac=0.3, p_uncond=0.0)
     out = detrand.normal("out", tuple(x0.shape), 4) * 0.5

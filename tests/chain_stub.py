@@ -15,12 +15,16 @@ class ChainStub(torch.nn.Module):
         self.c = torch.nn.Parameter(torch.ones(4 * scale))
         self.num_classes = 0
         self.log = []
-        self.active = None
+        self._active = None
         self.segs = [("c", ["c"]), ("b", ["b"]), (None, ["a"])]          # backward order
 
     def _chain_begin(self, run, tape, dout, need_dx):
-        if self.active is not None and self.active is not run:
-            self.active.drain()
+        other = self._active() if self._active is not None else None     # (a weak reference, as models/unet.py::_chain_begin holds it)
+        if other is not None and other is not run and not other.finished:
+            if other.task_id == run.task_id:
+                other.drain()
+            else:
+                other.stop_early()
         G = {k: torch.empty_like(p) for k, p in self.named_parameters()}
         s = float(dout.sum())
 
@@ -40,12 +44,17 @@ class ChainStub(torch.nn.Module):
                 return dout * 5 if need_dx else None
             finally:
                 self.log.append("closed")
-        self.active = run
+        import weakref
+        self._active = weakref.ref(run)
         return gen(), G, False
 
     def _chain_end(self, run):
-        if self.active is run:
-            self.active = None
+        if self._active is not None and self._active() in (run, None):
+            self._active = None
+
+    @property
+    def active(self):
+        return self._active() if self._active is not None else None
 
     def _chain_token(self, device):
         return torch.zeros(1)

@@ -24,7 +24,9 @@ def fixed_batch(cfg, B, R, steps):
     return out
 
 
-def run(rank, world, B, steps, dev="cuda", accum=1):
+def run(rank, world, B, steps, dev="cuda", accum=1, plan=None):
+    """plan (or None): per step one letter per SHARD of the batch (shard = rank * accum + micro-batch; world * accum letters): 'L' = the shard
+    is stepped with its labels, 'N' = with y = None (no class embedding at all: reference unet.py:289)"""
     import v_diffusion
     from v_diffusion.trainer import HotPathTrainer
     from oracle.cases import CIFAR_COND, make_weights
@@ -45,13 +47,15 @@ def run(rank, world, B, steps, dev="cuda", accum=1):
         part = []
         for a in range(accum):
             rows = slice(rank * per + a * mb, rank * per + (a + 1) * mb)
-            part.append(tr.step(x0[rows].to(dev), y[rows].to(dev), update=a == accum - 1, t=t[rows].to(dev), noise=noise[rows].to(dev)))
+            labelled = plan is None or plan[s][rank * accum + a] == "L"
+            part.append(tr.step(x0[rows].to(dev), y[rows].to(dev) if labelled else None, update=a == accum - 1, t=t[rows].to(dev),
+                                noise=noise[rows].to(dev)))
         losses.append(float(sum(part) / accum))
         if s == 0:
             g1 = tr.flat.g.detach().cpu().clone()
     torch.cuda.synchronize()
     return dict(p0=p0, p=tr.flat.p.detach().cpu(), ema=tr.flat.ema.detach().cpu(), g1=g1, losses=losses,
-                buckets=len(tr.reducer.bounds), reducer_active=tr.reducer.active)
+                buckets=len(tr.reducer.bounds), reducer_active=tr.reducer.active, cls_steps=tr.flat.cls_steps, steps=tr.flat.step_count)
 
 
 if __name__ == "__main__":
@@ -60,18 +64,20 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--accum", type=int, default=1)
+    ap.add_argument("--plan", default="", help="e.g. LN,NN,NL: per step, which shards pass labels (L) and which y = None (N)")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = run(rank, world, a.batch, a.steps, accum=a.accum)
+    res = run(rank, world, a.batch, a.steps, accum=a.accum, plan=a.plan.split(",") if a.plan else None)
     # every rank must hold the same replica after the update (DDP invariant)
     ref = res["p"].clone().cuda()
     dist.broadcast(ref, src=0)
     same = torch.equal(ref.cpu(), res["p"])
     flags = [None] * world
-    dist.all_gather_object(flags, same)
+    dist.all_gather_object(flags, (same, res["cls_steps"]))
     if rank == 0:
-        res["replicas_identical"] = all(flags)
+        res["replicas_identical"] = all(f[0] for f in flags)
+        res["cls_steps_per_rank"] = [f[1] for f in flags]
         torch.save(res, a.out)
     dist.destroy_process_group()

@@ -80,6 +80,38 @@ _hip.AUTOGRAD_CHAIN = True
 del ddp, opt, shadow, model
 torch.cuda.empty_cache()
 
+# ---- the same loop with the two-line opt-in (v_diffusion.optim): FusedAdamW instead of torch.optim.AdamW, v_diffusion.optim.EMA instead of the
+# reference's per-parameter EMA; clip_grad_norm_, LambdaLR and DDP stay torch's
+from v_diffusion.optim import FusedAdamW, EMA   # noqa: E402
+model = bench.build_model(dev, cfg=bench.CIFAR).train()
+opt = FusedAdamW(model.parameters(), lr=2e-4, betas=(0.9, 0.999), weight_decay=0.001)
+ddp = DDP(model, device_ids=[0])
+sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda t: min((t + 1) / 1000, 1.0))
+ema = EMA(model, decay=0.9999)
+
+
+def fused_step(clip=True):
+    t = torch.rand((B,), dtype=torch.float64, device=dev, generator=gen)
+    noise = torch.empty_like(x).normal_(generator=gen)
+    loss = diffusion.train_loss(ddp, x_0=x, t=t, y=y.clone(), noise=noise).mean()
+    loss.backward()
+    if clip:
+        torch.nn.utils.clip_grad_norm_(ddp.parameters(), max_norm=1.0)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    sched.step()
+    ema.update()
+    return loss
+
+
+ms = timeit(fused_step)
+print(f"reference-style loop with v_diffusion.optim.FusedAdamW + EMA (DDP 1-rank RCCL, torch clip_grad_norm_ kept): {ms:.2f} ms per step = {B / ms * 1e3:.0f} img/s", flush=True)
+opt.param_groups[0]["max_grad_norm"] = 1.0
+ms = timeit(lambda: fused_step(clip=False))
+print(f"  ... with the clip inside FusedAdamW(max_grad_norm=1.0) instead of clip_grad_norm_: {ms:.2f} ms per step = {B / ms * 1e3:.0f} img/s", flush=True)
+del ddp, opt, ema, model
+torch.cuda.empty_cache()
+
 # ---- the flat-buffer trainer on the same model / batch
 model = bench.build_model(dev, cfg=bench.CIFAR).train()
 tr = HotPathTrainer(model, gd(), lr=2e-4, weight_decay=0.001, warmup=1000, grad_norm=1.0, ema_decay=0.9999, use_ema=True)

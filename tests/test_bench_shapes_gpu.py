@@ -528,8 +528,17 @@ def test_cifar_train_step_b64_vs_oracle():
     if _hip.WINO:           # every residual-block convolution of this network is served by the Winograd kernels
         # 54 forward launches + 54 input gradients, of which the 16 at 32x32 and the 18 at 16x16 take the F(4x4,3x3) kernel (VD_WINO43=0: none)
         # (round 4: the same 34 layers run their FORWARD pass through the F(4x4,3x3) kernel too; VD_WINO43_FWD=0: none)
-        n43 = 34 if _hip.WINO43 else 0
-        n43f = 34 if _hip.WINO43_FWD else 0
+        # (under the product default the occupancy rule decides per geometry: at B = 64 the sixteen 32x32 layers keep F(4x4,3x3) -- 512 items, two
+        #  rounds -- and the eighteen 16x16 layers go to the finer F(2x2,3x3) items; VD_WINO43_OCC=0, set by
+        #  test_train_steps_through_the_f43_kernels_in_subprocess, sends all 34 through F(4x4,3x3))
+        # layers by (image size, channels on the N side of the Winograd GEMM): forward N = Cout = 256 everywhere; input gradient N = Cin = 256, or 512
+        # for the four skip-concatenating convolutions of each up level (twice the work items: they keep F(4x4,3x3) at 16x16 under the rule)
+        pf = lambda hw, n: int(_hip.wino43_preferred(B, hw, hw, n))
+        n43f_rule = 16 * pf(32, 256) + 18 * pf(16, 256)
+        n43_rule = 12 * pf(32, 256) + 4 * pf(32, 512) + 14 * pf(16, 256) + 4 * pf(16, 512)
+        assert (n43f_rule, n43_rule) == ((34, 34) if not _hip.WINO43_OCC else (16, 20)), (n43f_rule, n43_rule)
+        n43 = n43_rule if _hip.WINO43 else 0
+        n43f = n43f_rule if _hip.WINO43_FWD else 0
         assert (wino_calls[0], w43_calls[0], w43f_calls[0]) == (108 - n43 - n43f, n43, n43f) and not any(k == "conv" for k, _ in seen), \
             (wino_calls, w43_calls, w43f_calls, sorted(seen))
         # B = 64: the 32x32 (4096 tiles) and 16x16 layers (1024) take the F(4x4,3x3) weight gradient, 8x8 (256 tiles) the fused F(2x2,3x3) kernel

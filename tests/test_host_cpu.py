@@ -514,6 +514,42 @@ def test_autograd_chain_two_forwards_one_backward_and_frozen_prefix():
     assert "kernels a" not in m2.log and m2.log[-1] == "closed" and m2.active is None
 
 
+def test_autograd_chain_abandoned_backward_is_closed_not_drained():
+    """round-5 advice: a backward that stops between nodes (a parameter hook raised) leaves a suspended pass behind.  Nothing but the autograd
+    graph may keep it alive: once the graph is gone the pass closes its generator (the engine's side stream / arena state is released, the
+    tape freed), and the next backward starts clean instead of first running the stale pass to completion"""
+    import gc
+    m = _ChainStub()
+    h = m.b.register_hook(lambda g: (_ for _ in ()).throw(RuntimeError("hook failed")))
+    x = torch.ones(2, 3)
+
+    def failing_step():                                  # (its own frame: the exception and its traceback -- which reference the pass -- die with it)
+        out = m(x)
+        try:
+            out.sum().backward()
+        except RuntimeError as e:
+            assert "hook failed" in str(e)
+            return True
+        return False
+    assert failing_step()
+    assert m.log == ["kernels c", "kernels b-part", "kernels b"], m.log           # suspended behind segment b; segment a never ran
+    h.remove()
+    gc.collect()
+    # (PyTorch keeps the graph of a failed backward call alive until the next call on the thread starts: the pass may still be around here)
+    m.log.clear()
+    m.zero_grad(set_to_none=True)
+    m(x).sum().backward()                                                             # a clean pass: the old one is CLOSED, not run to its end
+    assert m.log.count("kernels a") == 1 and m.log.count("kernels c") == 1 and m.log.count("closed") == 2, m.log
+    assert torch.equal(m.a.grad, torch.full((3,), 18.0)) and m.active is None
+    # a call that never reaches the pass's last nodes (autograd.grad over the last segment's parameters only): closed when its graph goes
+    m3 = _ChainStub()
+    o = m3(x)
+    (g,) = torch.autograd.grad(o.sum(), [m3.c])
+    del o
+    gc.collect()
+    assert m3.log == ["kernels c", "closed"] and m3.active is None, m3.log
+
+
 def test_grad_segments_cover_the_completion_order():
     """the cut points of the chain are the engine's progress points; segments partition completion_order() in order"""
     import v_diffusion

@@ -296,6 +296,40 @@ __global__ void thin_wgrad_finish_kernel(const float* g, int Cout_w, int Cin, in
 
 }  // namespace
 
+// ---- clock / matrix-rate calibration (bench.py: a figure lines from different boxes can be normalised by).  A fixed register-only loop of
+// v_mfma_f32_16x16x4_f32 on every CU (8 waves per CU, two per SIMD, 16 independent accumulators per wave, operands drawn from `seed` so
+// that the data is not trivial -- the part's clock depends on it); lane 0 of every workgroup stamps s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) around the loop: in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz, rate = FLOPs / wall time.
+namespace {
+__global__ __launch_bounds__(512) void mfma_calibrate_kernel(float* sink, unsigned long long* stamps, int iters, unsigned seed) {
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned h = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    float a = (float)(h & 0xffff) * (1.0f / 65536.0f) - 0.5f, b = (float)(h >> 16) * (1.0f / 65536.0f) - 0.5f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32((i & 1) ? a : b, (i & 2) ? a : b, acc[i], 0, 0, 0);
+        a = a * 0.999f + 1e-4f;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123456.789f) sink[0] = s;                     // (keeps the loop; never true for these operands)
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+}  // namespace
+
+extern "C" int vd_mfma_calibrate(float* sink, unsigned long long* stamps, int32_t blocks, int32_t iters, uint32_t seed, void* stream) {
+    VD_REQUIRE(sink && stamps && blocks > 0 && iters > 0, "vd_mfma_calibrate: bad arguments");
+    hipLaunchKernelGGL(mfma_calibrate_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, sink, stamps, iters, seed);
+    VD_LAUNCH_CHECK("mfma_calibrate_kernel");
+    return 0;
+}
+
 extern "C" int vd_images_to_uint8_hwc(const float* x_nchw, uint8_t* out, int32_t n, int32_t C, int32_t HW, void* stream) {
     hipLaunchKernelGGL(to_uint8_hwc_kernel, dim3(grid_for((long long)n * C * HW)), dim3(256), 0, (hipStream_t)stream, x_nchw, out,
                        n, C, (long long)HW);

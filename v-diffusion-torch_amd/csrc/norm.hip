@@ -546,15 +546,27 @@ struct FusedBwdArgs {
     // pixels each; they exchange their per-channel partial sums through xbuf [unit][sibling][2][128] and meet at cnt[unit] (zeroed by the
     // launcher).  units = nimg * C / CS, numbered image-major.
     int nsplit; float* xbuf; unsigned* cnt;
+    unsigned* spin_max;          // -DVD_PROBES builds only (vd_gn_set_spin_probe): the longest sibling wait of a launch, in spin iterations
 };
 
-// SPLIT: the 64x64 layers (CelebA: 13.2 ms per step through the two-pass form, which reads dy and x twice).  Workgroup ids are laid out
-// so that the siblings of a unit are 8 ids apart -- dispatched within the same few dozen workgroups and, with the round-robin XCD
-// assignment, on the same XCD -- but correctness does not rest on that: the exchange uses agent-scope (sc1) stores / loads / atomics,
-// which are coherent across the XCDs' L2s, ordered by completion (s_waitcnt vmcnt(0) in front of the counter increment), NOT by
-// release / acquire fences: on this part an agent-scope release writes back the whole L2 of the XCD, in the middle of everybody's dx
-// stream (the cooperative-launch form of round 4 lost 5x that way).  In-order dispatch makes the spin safe: siblings sit next to each
-// other in the dispatch queue, and a workgroup only ever waits for ids within 24 of its own.
+// SPLIT: the 64x64 layers (CelebA: 13.2 ms per step through the two-pass form, which reads dy and x twice).  The siblings of a unit are
+// 8 logical ids apart (with the round-robin XCD assignment of in-order dispatch: on the same XCD); a set of 8 units x nsplit siblings is
+// 8 nsplit CONSECUTIVE logical ids.  The exchange uses agent-scope (sc1) stores / loads / atomics, which are coherent across the XCDs'
+// L2s, ordered by completion (s_waitcnt vmcnt(0) in front of the counter increment), NOT by release / acquire fences: on this part an
+// agent-scope release writes back the whole L2 of the XCD, in the middle of everybody's dx stream (the cooperative-launch form of
+// round 4 lost 5x that way).
+// Forward progress of the spin rests on the dispatcher, and says so: workgroups are dispatched in id order, round-robin over the 8 XCDs
+// (observed behaviour of this part, MI355X_MICROARCH.md, not a HIP guarantee), so the nsplit siblings of a unit -- ids congruent mod 8 --
+// land on ONE XCD, next to each other in its queue, and a sibling set (8 units x nsplit workgroups = 8 nsplit consecutive ids, NOT
+// "within 24" as the round-5 comment said: up to 248 ids apart at nsplit = 32) fills every XCD with whole units.  The launcher takes this
+// form only when every XCD can hold a unit's siblings twice over (8 nsplit x 2 <= resident workgroups of this kernel on the CUs that are not
+// reserved: hipOccupancyMaxActiveBlocksPerMultiprocessor; round-5 advice), so spinners cannot occupy every slot of an XCD while a sibling waits
+// in the queue; otherwise it falls through to the two-pass form.  Kernels of other streams only delay siblings, they do not wait for us.
+// (Round 6, built and dropped: logical ids taken as TICKETS at workgroup start, to be independent of dispatch order.  It DEADLOCKS: start order
+//  scatters a unit's siblings over the XCDs, an XCD fills up with spinners whose siblings have not started, and the in-order dispatcher --
+//  whose next workgroup is pinned to that XCD by the round-robin -- stops handing out work to the whole device.  The device-wide atomic
+//  itself is fine: tests/probe/xcd_atomic.hip, 4096 unique tickets.)  If a sibling never arrives the spin is bounded and the unit's results
+// are NaN: loud, not late.  tests/test_multigpu_path_gpu.py soaks it beside side-stream kernels and 1-rank RCCL collectives.
 template <int NPT, int TPB, bool NT = false, bool SPLIT = false>
 __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f) {
     __shared__ float red[TPB][8];
@@ -675,12 +687,14 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_fetch_add(f.cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (bounded: a sibling that never arrives -- impossible with in-order dispatch -- must not hang the device: ~1 s, then the
-            //  poisoned counter makes every later reader of this unit leave too and the results are visibly wrong, not late)
-            for (unsigned spin = 0; __hip_atomic_load(f.cnt + unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)f.nsplit; ++spin) {
+            // (bounded: a sibling that never arrives -- ruled out by in-order dispatch + the launcher's residency check -- must not hang the
+            //  device: ~1 s, then the poisoned counter makes every later reader of this unit leave too and the results are visibly wrong, not late)
+            unsigned spin = 0;
+            for (; __hip_atomic_load(f.cnt + unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)f.nsplit; ++spin) {
                 __builtin_amdgcn_s_sleep(8);
                 if (spin > (1u << 22)) { __hip_atomic_fetch_add(f.cnt + unit, 1u << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
+            if (VD_PROBE_BUILD && f.spin_max) atomicMax(f.spin_max, spin);
         }
         __syncthreads();
         if (tid < 2 * CS) {
@@ -758,6 +772,11 @@ __global__ __launch_bounds__(TPB) void gn_bwd_fused_kernel(const FusedBwdArgs f)
     }
 }
 
+#ifdef VD_PROBES
+unsigned* g_gn_spin_probe = nullptr;     // probe library only (vd_gn_set_spin_probe)
+#else
+constexpr unsigned* g_gn_spin_probe = nullptr;
+#endif
 thread_local int g_last_gn_bwd = 0;   // NPT * 10000 + TPB (+ 1000000: non-temporal instantiation) of the last fused launch, -1 = two-pass form, 0 = no norm (plain resample)
 
 template <int TPB>
@@ -807,6 +826,9 @@ inline int pick_cb(int C) {           // channels handled by one reduction block
 
 }  // namespace
 
+#ifdef VD_PROBES
+extern "C" int vd_gn_set_spin_probe(unsigned* buf) { g_gn_spin_probe = buf; return 0; }
+#endif
 extern "C" size_t vd_gn_ws_bytes(int32_t nimg, int32_t HW, int32_t C) {
     const long long chunks = (HW + PPC - 1) / PPC;
     // partials + q table + per-image dgamma/dbeta terms
@@ -974,11 +996,19 @@ static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int6
                     if (HW % k == 0 && (HW / k + (1024 / (CS / 4)) - 1) / (1024 / (CS / 4)) <= 8) { nsplit = k; break; }
                 const long long units = (long long)nimg * (C / CS), upad = (units + 7) / 8 * 8;
                 const size_t cnt_bytes = ((size_t)upad * sizeof(unsigned) + 255) / 256 * 256;
+                // residency check (round-5 advice): a sibling set (8 units x nsplit workgroups, one unit's siblings per XCD) must fit twice over
+                static const int split_occ = [] {
+                    int occ = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gn_bwd_fused_kernel<8, 1024, true, true>, 1024, 0) != hipSuccess) occ = 0;
+                    return occ;
+                }();
+                const long long resident = (long long)split_occ * vd_persistent_cus();
+                if (8LL * nsplit * 2 > resident) nsplit = 0;
                 const size_t need = cnt_bytes + (size_t)units * nsplit * 256 * sizeof(float);
                 const size_t avail = ((size_t)nimg * p.chunks * 2 * C + (size_t)nimg * 3 * C) * sizeof(float);     // (in front of the pgb region)
                 if (nsplit && need <= avail && upad * nsplit < (1LL << 31)) {
                     FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS, nsplit, reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cnt_bytes),
-                                      reinterpret_cast<unsigned*>(ws)};
+                                      reinterpret_cast<unsigned*>(ws), g_gn_spin_probe};
                     VD_REQUIRE(hipMemsetAsync(ws, 0, cnt_bytes, st) == hipSuccess, "vd_gn_apply_bwd: hipMemsetAsync of the sibling counters failed");
                     const dim3 grid((unsigned)(upad * nsplit));
                     g_last_gn_bwd = 8 * 10000 + 1024 + 1000000 + 100000000 * nsplit;
@@ -993,7 +1023,7 @@ static int gn_apply_bwd_impl(const float* dy, int64_t lddy, const float* x, int6
                 }
             }
             if (npt <= 8) {
-                FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS, 1, nullptr, nullptr};
+                FusedBwdArgs f = {a, gamma, beta, film, dfilm, pgb, G, CS, 1, nullptr, nullptr, nullptr};
                 dim3 grid(C / CS, nimg);
                 if (TPB == 1024) launch_fused_bwd<1024>(npt, grid, st, f); else launch_fused_bwd<256>(npt, grid, st, f);
                 VD_LAUNCH_CHECK("gn_bwd_fused_kernel");

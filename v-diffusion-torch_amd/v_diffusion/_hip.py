@@ -37,6 +37,7 @@ _SIGNATURES = {
     "vd_last_error": (C.c_char_p, []),
     "vd_set_reserved_cus": (C.c_int, [_i32]),
     "vd_reserved_cus": (C.c_int, []),
+    "vd_mfma_calibrate": (C.c_int, [_vp, _vp, _i32, _i32, C.c_uint32, _vp]),
     "vd_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "vd_gemm_last_tile": (C.c_int, []),
     "vd_gemm_split_forms": (C.c_int, []),
@@ -128,7 +129,7 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES)
 # extra entry points of libvdiff_hip_probe.so (built with -DVD_PROBES; tests/probe/*.py load it through VDIFF_HIP_LIB): bound when
 # the loaded library has them, absent from the product library
-PROBE_EXPORTS = {"vd_wino_set_probe": (C.c_int, [_vp]), "vd_wino43_set_probe": (C.c_int, [_vp])}
+PROBE_EXPORTS = {"vd_wino_set_probe": (C.c_int, [_vp]), "vd_wino43_set_probe": (C.c_int, [_vp]), "vd_gn_set_spin_probe": (C.c_int, [_vp])}
 
 _lib = None
 
@@ -334,6 +335,29 @@ def conv3x3_wino(x, ldx, U, bias, y, ldy, nimg, H, W, Cin, Cout, res=None, ldres
             else:
                 t.name = t.name.format(tw=k // 2000, ns=(k // 2) % 1000, st="true" if k & 1 else "false")
             _note_bytes(t.name, 4.0 * (nimg * H * W * (Cin + Cout + (Cout if res is not None else 0)) + 16 * Cout * Cin))
+
+
+def mfma_calibrate(seconds=1.5, blocks=256, iters=20000):
+    """Run the register-only fp32 MFMA loop of vd_mfma_calibrate back to back for `seconds` (the part's clock settles under load) and
+    return (in-kernel clock in MHz, TFLOP/s) of the last launch: a figure bench lines from different boxes can be normalised by."""
+    import time
+    sink = torch.zeros(1, device="cuda")
+    stamps = torch.zeros(2 * blocks, dtype=torch.int64, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_end = time.perf_counter() + seconds
+    ms = 0.0
+    while True:
+        e0.record()
+        _check(lib().vd_mfma_calibrate(sink.data_ptr(), stamps.data_ptr(), blocks, iters, 12345, stream()), "vd_mfma_calibrate")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        if time.perf_counter() >= t_end:
+            break
+    st = stamps.view(blocks, 2).double().cpu()
+    mhz = float((st[:, 0] / st[:, 1].clamp(min=1)).median()) * 100.0
+    tflops = blocks * 8 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12
+    return mhz, tflops
 
 
 WINO43 = os.environ.get("VD_WINO43", "1") != "0"  # A/B switch: 0 keeps the input gradients on F(2x2,3x3)

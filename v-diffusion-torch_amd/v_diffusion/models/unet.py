@@ -93,11 +93,13 @@ class _BackwardRun:
         self.no_labels = False
         self.reached = -1                  # index (backward order) of the last segment whose gradients are final
         self.finished = False
+        self.task_id = None                # the autograd graph task (one ``backward()`` / ``autograd.grad`` call) this pass runs inside
 
     def start(self, dout):
         if self.tape is None:
             raise RuntimeError("UNet backward called twice (the tape is freed after the first backward)")
         tape, self.tape = self.tape, None
+        self.task_id = torch._C._current_graph_task_id()
         self.gen, self.G, self.no_labels = self.model._chain_begin(self, tape, dout, self.need_dx)
 
     def advance(self, j):
@@ -143,6 +145,20 @@ class _BackwardRun:
     def _end(self):
         self.finished, self.gen = True, None
         self.model._chain_end(self)
+
+    def __del__(self):
+        # an abandoned pass (its autograd graph was freed before the last node ran): close the engine's generator at the yield it stands
+        # at instead of leaving its tape, gradient tensors and side-stream state to whoever starts the next backward
+        gen = self.gen
+        if gen is not None and not self.finished:
+            try:
+                gen.close()
+            except Exception:
+                pass
+            try:
+                self._end()
+            except Exception:
+                pass
 
 
 class _SegFn(torch.autograd.Function):
@@ -256,6 +272,7 @@ class UNet(nn.Module):
         self.out_conv = Sequential(GroupNorm32(chs[0]), nn.SiLU(), Conv2d(chs[0], out_channels, 3, 1, 1, init_scale=0.))
         self._engine = None
         self._flat_grad_views = None
+        self._grad_pool = {}                # per-parameter gradient slots of the autograd path, see _grad_targets
         self._grads_ready_hook = None
         self._tokens = {}
 
@@ -268,9 +285,34 @@ class UNet(nn.Module):
         return self._engine
 
     def _grad_targets(self):
+        """the tensors the backward kernels write the parameter gradients into.  The flat-buffer trainer installs its own views
+        (trainer.FlatState).  Otherwise (autograd path: ``loss.backward()``, ``DDP(model)``) every parameter has a persistent gradient SLOT and
+        autograd is handed a fresh alias of it: ``AccumulateGrad`` keeps a gradient tensor nobody else holds instead of cloning it, so
+        ``param.grad`` ends up in the slot and ``zero_grad(set_to_none=True)`` only drops a reference -- no 243 MB / 1.07 GB of allocations
+        per step (with the side stream's ``record_stream`` holds the caching allocator could not recycle them in time: 78.8 -> 65.8 ms per step
+        of the reference-style loop, tests/probe/ddp_style_step.py).
+          * default: one tensor per parameter with its OWN storage; it is handed out only while nothing but this module references that
+            storage (a ``.grad`` that was not reset -- gradient accumulation -- or a gradient tensor the caller kept get an ordinary fresh
+            tensor, exactly as before);
+          * a parameter owned by v_diffusion.optim.FusedAdamW: a view of the optimizer's flat gradient buffer whenever ``param.grad`` is
+            None (the optimizer's documented contract: gradients live in its buffer until the next backward, as with DDP's
+            ``gradient_as_bucket_view=True``)."""
         if self._flat_grad_views is not None:
             return self._flat_grad_views
-        return {k: torch.empty_like(p) for k, p in self.named_parameters()}
+        pool, use_count = self._grad_pool, torch._C._storage_Use_Count
+        out = {}
+        for k, p in self.named_parameters():
+            slot = getattr(p, "_vd_flat", None)
+            opt = slot[0]() if slot is not None else None
+            if opt is not None:
+                out[k] = opt.g[slot[1]:slot[1] + p.numel()].view_as(p) if p.grad is None else torch.empty_like(p)
+                continue
+            t = pool.get(k)
+            if t is None or t.device != p.device or t.shape != p.shape:
+                t = pool[k] = torch.empty(p.shape, dtype=p.dtype, device=p.device)
+            # 2 = this module's tensor + the temporary Python storage object of this very query: nobody else holds the memory
+            out[k] = t.detach() if use_count(t.untyped_storage()._cdata) == 2 else torch.empty_like(p)
+        return out
 
     def _dout_nhwc(self, dout):
         """NCHW output gradient -> the engine's NHWC layout, channels padded to a multiple of 4 (padding never read as data)"""
@@ -283,18 +325,26 @@ class UNet(nn.Module):
     # ---- chain of autograd nodes (see _SegFn)
     def _chain_begin(self, run, tape, dout, need_dx):
         eng = self.engine()
-        other = eng._active_run
-        if other is not None and other is not run:
-            other.drain()
+        # the pass in flight is held through a weak reference (round-5 advice): a run whose graph is gone -- backward stopped between nodes
+        # because a hook raised, or autograd.grad over a subset pruned the upstream nodes -- must not be kept alive (its tape is GBs of
+        # activations) nor be run to completion here; a run that still has live nodes (two forwards, one backward) is drained first
+        other = eng._active_run() if eng._active_run is not None else None
+        if other is not None and other is not run and not other.finished:
+            if other.task_id == run.task_id:
+                other.drain()               # two forwards inside ONE backward call: finish the first pass, its remaining nodes find their gradients
+            else:
+                other.stop_early()          # left over from an EARLIER backward call (it raised, or it never reached the pass's last nodes): its
+                                            # nodes can no longer run -- PyTorch keeps a failed call's graph alive until the next call starts
         G = self._grad_targets()
         no_labels = bool(self.num_classes) and tape["embed"]["yn"] is None
         gen = eng.backward_steps(tape, self._dout_nhwc(dout), G, need_dx=need_dx, join=True)
-        eng._active_run = run
+        import weakref
+        eng._active_run = weakref.ref(run)
         return gen, G, no_labels
 
     def _chain_end(self, run):
         eng = self._engine
-        if eng is not None and eng._active_run is run:
+        if eng is not None and eng._active_run is not None and eng._active_run() in (run, None):
             eng._active_run = None
 
     def _chain_token(self, device):
