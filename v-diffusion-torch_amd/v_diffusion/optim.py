@@ -52,7 +52,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 p._vd_flat = (weakref.ref(self), o)                         # models/unet.py::_grad_targets and EMA look for this
         self.steps = 0                  # updates of the parameters that always receive gradients
         self.lag_range = None           # (lo, hi): the ONE contiguous range that may see no gradient (class embedding), with its own count
-        self.lag_steps = 0
+        self.skipped = 0                # updates that range sat out (its per-parameter step of torch.optim.AdamW = steps - skipped)
+
+    @property
+    def lag_steps(self):
+        return self.steps - self.skipped
 
     def _gather_grads(self):
         """param.grad -> the flat gradient buffer (no copy for gradients that already lie in their slot); returns the index range without gradient"""
@@ -99,10 +103,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.lag_range is not None:
             r_lo, r_hi = self.lag_range
             if nograd is not None:
+                self.skipped += 1
                 r_mode = 1                                                  # torch.optim.AdamW skips parameters whose .grad is None
             else:
-                self.lag_steps += 1
-                r_mode, r_bc1, r_bc2 = 2, 1 - b1 ** self.lag_steps, 1 - b2 ** self.lag_steps
+                kl = self.lag_steps                                         # the range's own step count: updates it took part in
+                r_mode, r_bc1, r_bc2 = 2, 1 - b1 ** kl, 1 - b2 ** kl
         _hip.adamw_ema(self.p, self.g, self.m, self.v, None, self.gnorm_sq if max_norm > 0 else None, float(max_norm), lr, b1, b2, eps, wd,
                        1 - b1 ** k, 1 - b2 ** k, 1.0, r_lo, r_hi, r_mode, r_bc1, r_bc2)
         return loss
@@ -141,7 +146,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise NotImplementedError("FusedAdamW.load_state_dict: more than one group of lagging step counts")
             last = lag[-1]
             self.lag_range = (self._offs[lag[0]], min(self._offs[last] + (self._params[last].numel() + 3) // 4 * 4, self._n))
-            self.lag_steps = low
+            self.skipped = self.steps - low
 
 
 class EMA:
