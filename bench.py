@@ -203,8 +203,8 @@ def traffic_table(wl="cifar10"):
     """HBM bytes per launch from the committed PMC passes of THIS workload (profiles/parse_rocprof.py; separate --pmc passes cannot run
     inside the timed bench, so the figure is a tracked measurement of the same command and says which file it came from): newest round
     first; a workload without a PMC pass of its own gets no table (its `traffic` is null, never another workload's number)"""
-    names = {"cifar10": ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"),
-             "celeba": ("r05_celeba_traffic.json", "r04_celeba_traffic.json")}[wl]
+    names = {"cifar10": ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"),
+             "celeba": ("r06_celeba_traffic.json", "r05_celeba_traffic.json", "r04_celeba_traffic.json")}[wl]
     for name in names:
         try:
             return name, json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
@@ -279,7 +279,13 @@ def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, ba
     alg = T * 2 * W["fwd_gflop"] * SB / ds / 1e3                      # algorithmic TFLOP/s (2 x T x forward)
     exe = alg * exec_frac
     tname = "r06_sampler_traffic.json" if RES == 32 else "r06_celeba_sampler_traffic.json"
-    if not os.path.exists(os.path.join(ROOT, "profiles", tname)):
+    try:            # HBM bytes per launch of the dominant kernel from the committed PMC passes of the same sampler call (separate passes: not in the timed region)
+        tj = json.load(open(os.path.join(ROOT, "profiles", tname)))["kernels"]
+        if dominant is not None:
+            key = dominant["kernel"].split(" [")[0].split(" (+")[0]
+            dominant["traffic"] = tj[key]["hbm_bytes_per_launch"] if key in tj else None
+            dominant["traffic_source"] = f"profiles/{tname} (builder box)"
+    except Exception:
         tname = None
     return {"metric": f"ddim{T}_cfg_samples_per_sec", "value": round(world * SB / ds, 2), "unit": "images/s",
             "seconds_per_batch": round(ds, 3), "batch_per_gpu": SB, "unet_rows_per_step": 2 * SB, "w_guide": float(diffusion.w_guide),
@@ -290,7 +296,7 @@ def sample_once(diffusion, model, labels, SB, RES, T, W, device, rank, world, ba
                          "executed_share_of_algorithmic_flops": round(exec_frac, 4),
                          "recorded_gflop_per_unet_row": None if rec_gflop is None else round(rec_gflop, 2),
                          "dominant_kernel": dominant, "top_kernels": table,
-                         "kernel_table": "profiles/r06_sampler_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tests/probe/sample_only.py, the same sampler call)",
+                         "kernel_table": ("profiles/r06_sampler_kernel_stats.csv" if RES == 32 else "profiles/r06_celeba_sampler_kernel_stats.csv") + " (rocprofv3 --kernel-trace --stats of tests/probe/sample_only.py, the same sampler call)",
                          "traffic_table": None if tname is None else f"profiles/{tname}",
                          "note": "achieved = MFMA FLOPs executed over the whole sampler call (wall time, launch gaps included): the share comes from the "
                                  "launches two reverse steps of this run record (F(4x4,3x3) convolutions execute 1/4 of their algorithmic FLOPs, F(2x2,3x3) "
