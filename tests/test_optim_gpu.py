@@ -112,7 +112,7 @@ def test_fused_adamw_and_ema_follow_the_torch_loop():
     for k, v in mb.named_parameters():
         assert torch.equal(v.detach(), w0[k])
     # checkpoint round trip in torch.optim.AdamW's format (train_utils.py:317-331)
-    oc = FusedAdamW([p for p in copy.deepcopy(mb).parameters()], **kw)
+    oc = FusedAdamW([torch.nn.Parameter(p.detach().clone()) for p in mb.parameters()], **kw)
     oc.load_state_dict(ob.state_dict())
     assert oc.steps == ob.steps and oc.lag_steps == ob.lag_steps and oc.lag_range == ob.lag_range
     assert torch.equal(oc.m, ob.m) and torch.equal(oc.v, ob.v)
