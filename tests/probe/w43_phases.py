@@ -58,7 +58,8 @@ def report(name, fn, nwg, nkt, rounds):
         print(f"  gap between an item's last stamp and the next item's first: {gap:.0f} cycles; start of item round 1 across workgroups: spread {(rt.max() - rt.min()) / 100:.2f} us "
               f"(std {rt.std() / 100:.2f} us)")
     clk = ((t[:, 0, r - 1, 0] - t[:, 0, 0, 0]) / (t[:, 0, r - 1, 12] - t[:, 0, 0, 12]).clamp(min=1)).median().item() * 100 if r > 1 else 0
-    print(f"  shader clock while it runs: {clk:.0f} MHz (s_memtime ticks per s_memrealtime microsecond)")
+    print(f"  shader clock over this ONE stamped launch: {clk:.0f} MHz (s_memtime ticks per s_memrealtime microsecond; a handful of launches after idle -- "
+          f"the clock the chip holds under sustained load is profiles/r05_clock_by_kernel.txt: 2.37 GHz)")
 
 
 for nimg, Hh, Ww, Cin, Cout in ((128, 32, 32, 256, 256), (128, 32, 32, 512, 256), (128, 16, 16, 256, 256), (128, 64, 64, 192, 192)):
