@@ -433,6 +433,12 @@ def test_wino43_wgrad_at_bench_launches(H, case):
     S = H.lib().vd_wino43_wgrad_last_kernel()
     T = nimg * (Hh // 4) * (Ww // 4)
     assert S >= 1 and T / S <= 1536 + 1 or S == 24, (S, T)           # fp32 accumulation chains of at most ~1536 tiles
+    # which tile engine form ran the 36 plane GEMMs (the grouped launcher writes vd_gemm_last_tile): round 6's 256x256 / 8-wave kernel where
+    # Cout and Cin are multiples of 256 and a slab count fills its one-workgroup-per-CU rounds (16x16 and 32x32 layers), else the 128-row tiles
+    if H.lib().vd_gemm_split_forms() and __import__("os").environ.get("VD_PLANES256", "1") != "0":
+        code = _tile(H)
+        want256 = Cout % 256 == 0 and Cin % 256 == 0 and Hh >= 16
+        assert ((code["bm"], code["bn"]) == (256, 256)) == want256, (code, case)
     assert H.lib().vd_wino_wgrad_last_kernel() == w2_before, "routed to the F(2x2,3x3) kernel"
     dw2 = torch.empty_like(dw)
     H.conv3x3_wgrad(x, Cin, dy, Cout, nimg, Hh, Ww, Cin, Cout, dw2, Cin, Cout, dbias=None)

@@ -1061,6 +1061,141 @@ __global__ __launch_bounds__(256, (KT == 16 ? VD_SPL_BLOCKS : 2)) void gemm_spli
     gemm_dma_body<BM, BN, AK, BK, SPLITK, KT, TR, GROUPED, true>(p, gp);
 }
 
+// ---- 256x256 tiles for the grouped split-K weight-gradient launches (round 6; round-5 review item 3 i): C[e][m][n] = sum_k A_e[k][m] B_e[k][n]
+// with both operands row-contiguous ([k][rows]) -- the 36 planes of the F(4x4,3x3) weight gradient and the grouped 1x1 / linear weight
+// gradients whose M and N are multiples of 256.  Against the 128x128 forms of gemm_split_kernel: every operand element is read (and
+// split into its three bf16 pieces) ONCE per plane instead of twice, a wave's 64x128 tile carries 48 MFMAs per K tile of 16 (a barrier and
+// 4 LDS-DMA pieces per wave every 1 536 matrix cycles instead of every 768), and 6 split8 per 48 MFMAs is 5.5 plain vector instructions per
+// MFMA gap -- what hides beside v_mfma_f32_32x32x16_bf16 (tests/probe/mfma_bf16_fill.hip: up to ~5 per gap are free, 8 cost 15 cycles).
+// Workgroup = 8 waves (4 along m x 2 along n), one per CU; three LDS stages of (16 k x 256 m + 16 k x 256 n) fp32 = 96 KB, one barrier per K
+// tile, the DMA two tiles ahead.  Fragments: A rows interleaved by 2 (ds_read_b64: MFMA block a of a wave owns m = 2 i + a), B columns by 4
+// (ds_read_b128: block b owns n = 4 i + b) -- so a lane's four accumulator registers r of the four B blocks are four CONSECUTIVE columns of
+// one output row: the slab leaves as dwordx4 stores.  Same arithmetic as gemm_split_kernel (six bf16 piece products, fp32 accumulation in
+// the same k order inside a slab), same slab layout, same colsum partials: the reduce kernels and callers are unchanged.
+__global__ __launch_bounds__(512) void wgrad_planes256_kernel(const GemmArgs p, const GroupPtrs gp) {
+    constexpr int BM = 256, BN = 256, KTT = 16, NBUF = 3, STG = (BM + BN) * KTT;      // floats per stage
+    __shared__ __attribute__((aligned(1024))) float smem[NBUF * STG];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
+    const int tbx = blockIdx.x, tby = blockIdx.y, tbz = blockIdx.z;
+    const int m0 = tby * BM, n0 = tbx * BN;
+    const int e = tbz / p.group_S, slab = tbz - e * p.group_S;
+    const float* A = gp.A[e] + m0;
+    const float* B = gp.B[e] + n0;
+    const int kt_begin = slab * p.kt_per_split, kt_end = min(kt_begin + p.kt_per_split, p.kt_total);
+    float* C = p.C + (long long)tbz * p.slab_stride;
+
+    // DMA plan: a K tile is 16 rows of A and 16 rows of B, 1 KiB each; wave w copies rows w and w + 8 of both (lane l: floats 4l .. 4l+3)
+    auto issue = [&](int kt, int buf) {
+        float* as = smem + buf * STG;
+        float* bs = as + BM * KTT;
+        // the K tile's base goes into the descriptor (64-bit, scalar unit); past the slab's range the descriptor is empty: the DMA writes
+        // zeros into a stage nobody reads
+        const int rec = kt < kt_end ? (int)OOB : 0;
+        const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A + (p.a_kblk ? (long long)kt * p.a_kblk : (long long)kt * KTT * p.lda), rec);
+        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B + (p.b_kblk ? (long long)kt * p.b_kblk : (long long)kt * KTT * p.ldb), rec);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = wave + 8 * h;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(as + kk * BM), 16, lane * 16, kk * (int)p.lda * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(bs + kk * BN), 16, lane * 16, kk * (int)p.ldb * 4, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float csum[2] = {0.f, 0.f};
+    const bool do_cs = p.colsum != nullptr && tbx == 0 && (wave & 1) == 0;
+
+    if (kt_begin < kt_end) {
+        issue(kt_begin, 0);
+        issue(kt_begin + 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // tile kt_begin has landed (this wave's four newest pieces belong to the next one)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const float* as = smem + buf * STG;
+            const float* bs = as + BM * KTT;
+            // stage (buf + 2) % 3 held tile kt - 1: every wave finished reading it before the barrier that closed the previous iteration
+            issue(kt + 2, buf >= 1 ? buf - 1 : 2);
+            float fa[2][8];
+            f32x4 fbq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(as + (8 * lh + j) * BM + wm + 2 * li);
+                fa[0][j] = v[0]; fa[1][j] = v[1];
+                fbq[j] = *reinterpret_cast<const f32x4*>(bs + (8 * lh + j) * BN + wn + 4 * li);
+            }
+            bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) split8(fa[a], ah[a], am[a], al[a]);
+            if (do_cs) {
+                asm volatile("" ::: "memory");      // keep this a branch: if-converted, every wave of the launch ran the adds
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    csum[a] += ((fa[a][0] + fa[a][1]) + (fa[a][2] + fa[a][3])) + ((fa[a][4] + fa[a][5]) + (fa[a][6] + fa[a][7]));
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {        // B blocks two at a time: 24 registers of pieces live instead of 48
+                bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    float fb[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) fb[j] = fbq[j][2 * hb + b2];
+                    split8(fb, bh[b2], bm[b2], bl[b2]);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        f32x16& d = acc[a][2 * hb + b2];
+                        // (operands swapped as in the TR forms of the tile engine: D[i][j], i = B row = column n, j = A row = m)
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[b2], ah[a], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[b2], al[a], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[b2], am[a], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[b2], am[a], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm[b2], ah[a], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[b2], ah[a], d, 0, 0, 0);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // tile kt + 1 has landed; tile kt + 2 may still be in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the zero-fill DMAs past the range: nothing may land after the workgroup is gone)
+
+    if (do_cs) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float v = csum[a] + __shfl_xor(csum[a], 32, 64);
+            if (lh == 0) p.colsum[(long long)tbz * p.M + m0 + wm + 2 * li + a] = v;
+        }
+    }
+    // epilogue: D[i][j] of block (a, b): j = lane & 31 -> m = wm + 2 j + a; i = (r & 3) + 8 (r >> 2) + 4 lh -> n = wn + 4 i + b
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t crs = make_rsrc(C + (long long)m0 * p.N + n0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const unsigned rowb = (unsigned)(wm + 2 * li + a) * (unsigned)p.N * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const u32x4 u = {__float_as_uint(acc[a][0][r]), __float_as_uint(acc[a][1][r]), __float_as_uint(acc[a][2][r]), __float_as_uint(acc[a][3][r])};
+            __builtin_amdgcn_raw_buffer_store_b128(u, crs, (int)(rowb + (unsigned)(wn + 4 * i) * 4u), 0, 0);
+        }
+    }
+}
+
 // out (+)= sum over slabs; optional OIHW transposition for the conv weight gradient
 __global__ void reduce_slabs_kernel(const float* slabs, int S, long long slab_stride, int M, int N, float* out,
                                     long long ldo, int accumulate, float alpha, const float* cpart, float* colsum,
@@ -1393,6 +1528,23 @@ void launch_grouped(const GemmArgs& a, const GroupPtrs& gp, dim3 grid, hipStream
 }
 // 128x128 tiles of a grouped launch with at least this many workgroups take the KT = 16 form (32 KB of LDS: four workgroups per CU)
 constexpr long long GROUPED_K16_MIN_WGS = 768;
+// grouped weight-gradient launches whose M and N are multiples of 256 run wgrad_planes256_kernel (split forms only; VD_PLANES256=0: A/B switch)
+// when some slab count fills its one-workgroup-per-CU rounds to >= 85 % (same-box A/B, profiles/r06_planes256_ab.txt: -9 ... -10 % per launch at
+// 256 -> 256 and 512 -> 256 @32x32, +-0 @16x16; the 8x8 layers -- K = 512 tiles, at most two slabs of 36 ... 648 workgroups -- lose 10-40 % to round
+// quantisation and keep the 128x128 tiles, four workgroups per CU)
+static bool planes256(int count, int M, int N, int K) {
+    static const bool on = !(getenv("VD_PLANES256") && atoi(getenv("VD_PLANES256")) == 0);
+    if (!(on && split_forms() && M % 256 == 0 && N % 256 == 0 && K % 16 == 0)) return false;
+    const long long blocks = (long long)(M / 256) * (N / 256) * count, slots = vd_cu_count();
+    const int kmax = K / 256 > 1 ? K / 256 : 1;
+    double best = 0.0;
+    for (int sl = 1; sl <= 24 && sl <= kmax; ++sl) {
+        const long long wgs = blocks * sl, rounds = (wgs + slots - 1) / slots;
+        const double eff = (double)wgs / (double)(rounds * slots);
+        if (eff > best) best = eff;
+    }
+    return best >= 0.85;
+}
 
 }  // namespace
 
@@ -1404,9 +1556,11 @@ constexpr long long GROUPED_K16_MIN_WGS = 768;
  * work), with at least min_slabs slabs (shorter fp32 accumulation chains: the caller's accuracy budget) and at most max_slabs. */
 extern "C" int vd_gemm_grouped_wgrad_auto_split(int32_t count, int32_t M, int32_t N, int32_t K, int32_t min_slabs, int32_t max_slabs) {
     const int tile = choose_tile(M, N, false, (long long)count * 8, 0);
-    const long long blocks = (long long)((M + TILES[tile].bm - 1) / TILES[tile].bm) * ((N + TILES[tile].bn - 1) / TILES[tile].bn) * count;
-    // (128x128 tiles: long launches run the KT = 16 form, four workgroups per CU)
-    const long long slots = (long long)vd_cu_count() * (tile == 0 && blocks * (min_slabs > 1 ? min_slabs : 1) >= GROUPED_K16_MIN_WGS / 2 ? 4 : TILES[tile].per_cu);
+    const bool p256 = planes256(count, M, N, K);
+    const long long blocks = p256 ? (long long)(M / 256) * (N / 256) * count
+                                  : (long long)((M + TILES[tile].bm - 1) / TILES[tile].bm) * ((N + TILES[tile].bn - 1) / TILES[tile].bn) * count;
+    // (128x128 tiles: long launches run the KT = 16 form, four workgroups per CU; 256x256 tiles: one workgroup per CU)
+    const long long slots = (long long)vd_cu_count() * (p256 ? 1 : (tile == 0 && blocks * (min_slabs > 1 ? min_slabs : 1) >= GROUPED_K16_MIN_WGS / 2 ? 4 : TILES[tile].per_cu));
     int lo = min_slabs > 1 ? min_slabs : 1, hi = max_slabs > lo ? max_slabs : lo;
     const int kmax = K / 256 > 1 ? K / 256 : 1;                       // at least 8 K tiles per slab
     if (hi > kmax) hi = kmax;
@@ -1443,7 +1597,7 @@ int vd_gemm_grouped_wgrad_used_slabs(int32_t count, int32_t M, int32_t N, int32_
     const int S = splitk > 1 ? splitk : 1;
     const int tile = choose_tile(M, N, false, (long long)count * S, 0);
     const long long nm = (M + TILES[tile].bm - 1) / TILES[tile].bm, nn = (N + TILES[tile].bn - 1) / TILES[tile].bn;
-    const bool k16 = tile == 0 && nm * nn * count * S >= GROUPED_K16_MIN_WGS;
+    const bool k16 = planes256(count, M, N, K) || (tile == 0 && nm * nn * count * S >= GROUPED_K16_MIN_WGS);
     const int kt_total = k16 ? (K + 15) / 16 : (K + 31) / 32, per = (kt_total + S - 1) / S;
     return (kt_total + per - 1) / per;
 }
@@ -1475,8 +1629,9 @@ int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, flo
     VD_REQUIRE(dma_in_range(a), "vd_gemm_grouped_wgrad: operands outside the LDS-DMA kernel's range (alignment / row pitch)");
     const int tile = choose_tile(M, N, false, (long long)count * S, 0);
     const int tbm = TILES[tile].bm, tbn = TILES[tile].bn;
-    const long long nm = (M + tbm - 1) / tbm, nn = (N + tbn - 1) / tbn;
-    const bool k16 = tile == 0 && nm * nn * count * S >= GROUPED_K16_MIN_WGS;
+    const bool p256 = planes256(count, M, N, K);
+    const long long nm = p256 ? M / 256 : (M + tbm - 1) / tbm, nn = p256 ? N / 256 : (N + tbn - 1) / tbn;
+    const bool k16 = p256 || (tile == 0 && nm * nn * count * S >= GROUPED_K16_MIN_WGS);
     a.kt_total = k16 ? (K + 15) / 16 : (K + 31) / 32;
     a.kt_per_split = (a.kt_total + S - 1) / S;
     const int used = (a.kt_total + a.kt_per_split - 1) / a.kt_per_split;      // slabs that hold work (<= S)
@@ -1487,7 +1642,10 @@ int vd_gemm_grouped_wgrad_kblk(const float* const* A, const float* const* B, flo
     a.colsum = colsum ? cpart : nullptr;
     const dim3 grid((unsigned)nn, (unsigned)nm, (unsigned)(count * used));
     hipStream_t st = (hipStream_t)stream;
-    if (tile == 0 && k16) launch_grouped<128, 128, 16>(a, gp, grid, st);
+    if (p256) {
+        vd_g_last_tile = (((3 * 100 + 16) * 1000) + 256) * 1000 + 256;
+        hipLaunchKernelGGL(wgrad_planes256_kernel, grid, dim3(512), 0, st, a, gp);
+    } else if (tile == 0 && k16) launch_grouped<128, 128, 16>(a, gp, grid, st);
     else if (tile == 0) launch_grouped<128, 128>(a, gp, grid, st);
     else if (tile == 1) launch_grouped<128, 64>(a, gp, grid, st);
     else if (tile == 2) launch_grouped<64, 128>(a, gp, grid, st);
