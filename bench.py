@@ -41,7 +41,7 @@ PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
 def kernel_peak(kernel_name):
     """the matrix-core ceiling a kernel is priced against, in fp32-equivalent TFLOP/s: 157.3 for the fp32 MFMA instructions, dense bf16 / 6
     = 419.5 for the split-operand (bf16x3) forms of the tile engine"""
-    return PEAK_SPLIT_TFLOPS if "gemm_split" in kernel_name else PEAK_FP32_MFMA_TFLOPS
+    return PEAK_SPLIT_TFLOPS if ("gemm_split" in kernel_name or "planes256" in kernel_name) else PEAK_FP32_MFMA_TFLOPS
 CIFAR = dict(in_channels=3, hid_channels=256, out_channels=3, ch_multipliers=[1, 1, 1], num_res_blocks=3,
              apply_attn=[False, True, True], drop_rate=0.2, num_heads=1, num_classes=10, multitags=False)
 FWD_GFLOP_PER_IMG = 37.64              # SURVEY 8d: matmul-class FLOPs of one CIFAR UNet forward
@@ -420,7 +420,7 @@ def run_training(wl, B, steps, warmup, device, rank, world, barrier, sample_step
         # tiles) and the split-operand (bf16x3) forms of the tile engine; roofline_ms = the time the launches would take at their ceilings
         cls = {"fp32_mfma": [0.0, 0.0], "bf16x3_split": [0.0, 0.0]}
         for k, v in agg.items():
-            c = cls["bf16x3_split" if "gemm_split" in k else "fp32_mfma"]
+            c = cls["bf16x3_split" if ("gemm_split" in k or "planes256" in k) else "fp32_mfma"]
             c[0] += v[0] * executed_share(k) / 2; c[1] += v[1] / 2
         ideal_ms = sum(c[0] / (peak * 1e12) for c, peak in ((cls["fp32_mfma"], PEAK_FP32_MFMA_TFLOPS), (cls["bf16x3_split"], PEAK_SPLIT_TFLOPS))) * 1e3
         dom_peak = kernel_peak(dom)

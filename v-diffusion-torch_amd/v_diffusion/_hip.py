@@ -215,6 +215,8 @@ class _Timed:
             name = self.name.format(tile=f"{bm}, {bn}", kt=f"{kt}, {'true' if tr else 'false'}")
             if spl:
                 name = name.replace("gemm_dma_kernel", "gemm_split_kernel")
+            if spl and (bm, bn) == (256, 256):          # round 6: the 8-wave 256x256 form of the grouped weight-gradient launches (its rocprof name)
+                name = "wgrad_planes256_kernel" + name[name.index(">") + 1:]
             if kt == 0:
                 name = name.replace("gemm_dma_kernel", "gemm_kernel").replace(", 0, false>", ">")
             PROFILE.append((name, self.flops, self.e0, self.e1))
